@@ -1,0 +1,182 @@
+/* pedn.h -- C-ABI of the MI355X engine for PedNStream's per-timestep network_loading hot path.
+ *
+ * The reference is pure Python and has no FFI; this header is the boundary a maintainer binds with ctypes
+ * (see INTEGRATION.md).  Every entry point names the reference interface it replaces
+ * (paths relative to the reference tree):
+ *
+ *   pedn_create                  Network.__init__ / init_nodes_and_links          src/LTM/network.py:56-121,194-248
+ *                                Link.__init__ / Separator.__init__ state arrays   src/LTM/link.py:12-17,32-100,420-425
+ *   pedn_step / pedn_run         Network.network_loading(t)                        src/LTM/network.py:266-287
+ *                                (Node.assign_flows src/LTM/node.py:164-221, Link.cal_sending_flow src/LTM/link.py:216-370,
+ *                                 Link.cal_receiving_flow[_with_reverse] :372-416, Network.update_link_states
+ *                                 src/LTM/network.py:257-264, PathFinder.calculate_node_turning_fractions
+ *                                 src/LTM/path_finder.py:717-737)
+ *   pedn_set_demand              node.demand (origin arrays)                       src/LTM/network.py:130-139, node.py:176
+ *   pedn_set_od_weights          ODManager.od_flows / get_od_flow                  src/LTM/od_manager.py:22-54
+ *   pedn_set_turning_fractions   Network.update_turning_fractions_per_node         src/LTM/network.py:250-255
+ *   pedn_get_turning_fractions   node.turning_fractions                            src/LTM/node.py:11
+ *   pedn_set_width[s]            Link.front/back_gate_width, Separator.separator_width setters
+ *                                                                                   src/LTM/link.py:110-126,462-478
+ *   pedn_read                    the per-link history arrays read by callers       src/LTM/link.py:12-17,56,82-97
+ *   pedn_error_flags             raise ValueError / Warning sites                  src/LTM/link.py:345-346,365-366; node.py:192-194,218-219,237-238
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a negative PEDN_E_* code on
+ * failure, with a message retrievable through pedn_last_error().  Host pointers are borrowed for the duration of the
+ * call.  All device work of one handle is enqueued on one HIP stream; pedn_step/pedn_run are asynchronous, the
+ * read/flag calls synchronise.  Replicas are independent copies of the scenario stepped together; `replica` arguments
+ * accept PEDN_ALL (-1) for "every replica".
+ */
+#ifndef PEDN_H
+#define PEDN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEDN_ABI_VERSION 1
+#define PEDN_ALL (-1)
+#define PEDN_MAX_DEGREE 8 /* incident corridor slots per node handled by the node kernel */
+
+/* return codes */
+#define PEDN_OK 0
+#define PEDN_E_ARG (-1)     /* bad argument / inconsistent model description */
+#define PEDN_E_DEVICE (-2)  /* HIP runtime error */
+#define PEDN_E_MODEL (-3)   /* sticky per-replica model error, see pedn_error_flags */
+#define PEDN_E_NOMEM (-4)
+
+/* per-replica sticky error bits (pedn_error_flags) */
+#define PEDN_F_NEG_SENDING 1u /* negative sending flow            (link.py:345-346,365-366 ValueError) */
+#define PEDN_F_NEG_FLOW 2u    /* negative s / r / q at a node      (node.py:192-194,218-219,237-238 Warning) */
+#define PEDN_F_INDEX 4u       /* history index outside [-(T+1), T] (IndexError in the reference) */
+#define PEDN_F_NEG_BINOM 8u   /* binomial with n < 0               (numpy ValueError at link.py:382) */
+#define PEDN_F_SAME_STEP 16u  /* look-back of 0 steps: the reference result depends on node iteration order */
+
+/* RNG modes (oracle/rng_contract.py) */
+#define PEDN_RNG_PHILOX 0
+#define PEDN_RNG_MEANFIELD 1 /* binomial -> floor(n*p), normal -> 0 */
+
+/* width selectors */
+#define PEDN_W_FRONT 0
+#define PEDN_W_BACK 1
+#define PEDN_W_SEP 2
+
+/* history fields; f64 fields 0..6 have n_links + n_vlinks columns for ids 0..3 (virtual links keep only those) */
+enum {
+  PEDN_FIELD_INFLOW = 0,
+  PEDN_FIELD_OUTFLOW = 1,
+  PEDN_FIELD_CUM_INFLOW = 2,
+  PEDN_FIELD_CUM_OUTFLOW = 3,
+  PEDN_FIELD_SENDING = 4,
+  PEDN_FIELD_RECEIVING = 5,
+  PEDN_FIELD_GATE_REC = 6, /* back_gate_width_data (separator_width_data for separators) */
+  PEDN_FIELD_TRAVEL_TIME = 7,
+  PEDN_FIELD_AVG_TRAVEL_TIME = 8,
+  PEDN_FIELD_NUM_PED = 9,
+  PEDN_FIELD_DENSITY = 10,
+  PEDN_FIELD_SPEED = 11,
+  PEDN_FIELD_LINK_FLOW = 12,
+  PEDN_N_FIELDS = 13
+};
+
+/* Static, replica-independent description of one scenario (built by pednstream_amd/flatten.py).
+ * Node n owns slots node_slot_ptr[n] .. node_slot_ptr[n+1]-1; slot k of a node holds the incoming link
+ * slot_in_link[] and the outgoing link slot_out_link[] towards the same neighbour (reverse pair); a link index
+ * >= n_links denotes a virtual link (origin/destination side, always slot 0 of its node).
+ * Turning fractions of node n are node_turn_ptr[n] .. +m(m-1), source-major, destinations ascending skipping the
+ * source's own slot (node.py:274-280). */
+typedef struct pedn_model_desc {
+  int32_t abi_version;
+  int32_t n_nodes, n_links, n_vlinks, n_turns, n_demand, n_od;
+  int32_t T;      /* simulation_steps; histories have T+1 entries */
+  int32_t window; /* moving-average window W = round(100/dt)  (link.py:89) */
+  double dt;      /* unit_time */
+
+  const int32_t* node_kind;       /* [n_nodes] 0 one-to-one, 1 regular                 (network.py:141-167) */
+  const int32_t* node_slot_ptr;   /* [n_nodes+1] */
+  const int32_t* node_turn_ptr;   /* [n_nodes+1] */
+  const int32_t* node_demand_row; /* [n_nodes] row of `demand`, or -1 */
+  const int32_t* node_dyn;        /* [n_nodes] 1: turning fractions recomputed every step (path_finder.py:731-737) */
+  const int32_t* slot_in_link;    /* [n_slots] */
+  const int32_t* slot_out_link;   /* [n_slots] */
+
+  const int32_t* link_rev;    /* [n_links] reverse link */
+  const int32_t* link_sep;    /* [n_links] 1: Separator */
+  const int32_t* link_fd;     /* [n_links] 0 yperman, 1 greenshields, 2 smulders */
+  const int32_t* link_tau_sw; /* [n_links] round(length/(shockwave_speed*dt))  (link.py:380) */
+  const int32_t* link_fft;    /* [n_links] free_flow_tau                        (link.py:86) */
+  const float* link_tt0;      /* [n_links] travel_time[0]                       (link.py:83) */
+  const double *link_length, *link_width, *link_vf, *link_kc, *link_kj, *link_gamma, *link_act, *link_bi, *link_noise;
+  const double *front_gate0, *back_gate0, *sep_width0; /* [n_links] initial widths */
+
+  const double* tf_init; /* [n_turns] */
+  const double* demand;  /* [n_demand][T+1] */
+  const double* od_w;    /* [n_od][T+1] */
+
+  /* route-choice tables (all index ranges are global, CSR per node) */
+  double pf_temp, pf_alpha, pf_beta, pf_omega, pf_eps;
+  int32_t n_up, n_upod, n_grp, n_ent, n_pair;
+  const int32_t* node_up_ptr;   /* [n_nodes+1] -> upstream groups of the node              (up_od_probs, :599-615) */
+  const int32_t* up_od_ptr;     /* [n_up+1]    -> upod entries of one upstream */
+  const int32_t* upod_od;       /* [n_upod]    OD row in od_w */
+  const int32_t* node_grp_ptr;  /* [n_nodes+1] -> (od, up) softmax groups of the node       (turns_distances, :563) */
+  const int32_t* grp_ent_ptr;   /* [n_grp+1]   -> downstream entries of one group */
+  const int32_t* grp_allphys;   /* [n_grp]     1: every downstream is a physical link (f32 density branch, :581) */
+  const int32_t* ent_link;      /* [n_ent]     outgoing link of the entry, -1 = virtual     (:577-579) */
+  const double* ent_dist;       /* [n_ent]     remaining distance */
+  const int32_t* turn_pair_ptr; /* [n_turns+1] -> (entry, upod) products summed into one turning fraction (:668-686) */
+  const int32_t* pair_ent;      /* [n_pair] */
+  const int32_t* pair_upod;     /* [n_pair] */
+} pedn_model_desc;
+
+typedef struct pedn_sim pedn_sim;
+
+int pedn_abi_version(void);
+/* message of the last failing call on this thread (handle may be NULL for pedn_create failures) */
+const char* pedn_last_error(const pedn_sim* sim);
+
+int pedn_create(const pedn_model_desc* model, int32_t n_replicas, int32_t replica_offset, uint64_t seed,
+                int32_t rng_mode, int32_t device, pedn_sim** out);
+int pedn_destroy(pedn_sim* sim);
+
+/* values[n] -> demand[node][0..n-1] (rest zero); node is the model's node index, replica may be PEDN_ALL */
+int pedn_set_demand(pedn_sim* sim, int32_t node, int32_t replica, const double* values, int32_t n);
+/* values[T+1] -> OD weight row `od` (shared by all replicas) */
+int pedn_set_od_weights(pedn_sim* sim, int32_t od, const double* values, int32_t n);
+int pedn_set_turning_fractions(pedn_sim* sim, int32_t node, int32_t replica, const double* tf, int32_t n);
+int pedn_get_turning_fractions(pedn_sim* sim, int32_t node, int32_t replica, double* tf, int32_t n);
+int pedn_set_width(pedn_sim* sim, int32_t which, int32_t link, int32_t replica, double value);
+/* values[n_links][n_replicas] */
+int pedn_set_widths(pedn_sim* sim, int32_t which, const double* values);
+
+/* one step t in 1..T-1 for every replica; asynchronous */
+int pedn_step(pedn_sim* sim, int32_t t);
+/* steps t0 .. t1-1 enqueued back to back; asynchronous */
+int pedn_run(pedn_sim* sim, int32_t t0, int32_t t1);
+int pedn_synchronize(pedn_sim* sim);
+/* synchronises; flags[n_replicas] may be NULL; returns the OR over replicas (>= 0) or a negative code */
+int pedn_error_flags(pedn_sim* sim, uint32_t* flags);
+
+/* out[(t1-t0)][(link1-link0)][(rep1-rep0)] of the field's element type (f64 for ids 0..6, f32 otherwise) */
+int pedn_read(pedn_sim* sim, int32_t field, int32_t t0, int32_t t1, int32_t link0, int32_t link1, int32_t rep0,
+              int32_t rep1, void* out);
+
+/* zero-copy access for on-device consumers: HBM base pointer of a history field laid out
+ * [T+1][columns][replica_stride]; columns/replica_stride may be NULL */
+void* pedn_device_ptr(pedn_sim* sim, int32_t field, int64_t* columns, int64_t* replica_stride);
+/* hipStream_t the engine launches on */
+void* pedn_stream(pedn_sim* sim);
+
+/* HIP-event timing on the engine's stream: begin records an event, end records + synchronises and returns the
+ * elapsed milliseconds in *ms */
+int pedn_timer_begin(pedn_sim* sim);
+int pedn_timer_end(pedn_sim* sim, float* ms);
+
+/* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */
+int pedn_reset(pedn_sim* sim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEDN_H */

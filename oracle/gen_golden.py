@@ -1,0 +1,181 @@
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.  TEST INFRASTRUCTURE.
+
+Run in the build container (needs /root/reference):   python oracle/gen_golden.py [case ...]
+
+Every fixture is data only: inputs (scenario name or adjacency+params, demand arrays, RNG key, between-step
+mutations) and expected outputs (the 13 per-link history arrays, virtual-link arrays, turning-fraction history,
+setup-time tables).  Cases:
+  G1  kat_six_node            native numpy RNG known-answer numbers for config #1 (+ the gate-mutation variant)
+  G2  *_full                  injected-RNG full histories for the small scenarios
+  G3  *_prefix                injected-RNG prefixes for 45_intersections / delft / melbourne
+  G4  nine_meanfield          mean-field mode
+  G5  six_node_gate, forky    between-step gate mutations and externally imposed turning fractions
+  G2r nine_replicas           config #2: replicas 0..3 with per-replica demand and RNG key
+"""
+import hashlib
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_harness as rh  # noqa: E402  (sets NPY_DISABLE_CPU_FEATURES before numpy is imported)
+
+import numpy as np  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def tf_matrix(network, extras):
+    """[steps-1, n_turns] turning-fraction history in node order."""
+    cols = [extras["tf_hist"][int(nid)] for nid in network.nodes.keys()]
+    return np.concatenate(cols, axis=1)
+
+
+def save(case, static, state, extras, info):
+    os.makedirs(OUT, exist_ok=True)
+    payload = {}
+    payload.update({"static_" + k: v for k, v in static.items()})
+    payload.update({"state_" + k: v for k, v in state.items()})
+    if "tf" in extras:
+        payload["tf_hist"] = extras["tf"]
+    info = dict(info)
+    info["steps_run"] = extras["steps_run"]
+    info["draws"] = {str(k): int(v) for k, v in extras["draws"].items()}
+    info["numpy"] = np.__version__
+    payload["info_json"] = np.array(json.dumps(info))
+    path = os.path.join(OUT, case + ".npz")
+    np.savez_compressed(path, **payload)
+    print(f"{case}: {os.path.getsize(path) / 1024:.0f} KiB, draws {info['draws']}")
+
+
+def scenario_case(case, name, steps=None, seed=0, replica=0, mode="philox", np_seed=20261003, mutations=None,
+                  demand_override=None):
+    muts = mutations or []
+
+    def mutate(net, t):
+        for (mt, kind, u, v, val) in muts:
+            if mt == t:
+                if kind == "back_gate_delta":
+                    net.links[(u, v)].back_gate_width += val
+                elif kind == "back_gate_set":
+                    net.links[(u, v)].back_gate_width = val
+                elif kind == "separator_set":
+                    net.links[(u, v)].separator_width = val
+                else:
+                    raise ValueError(kind)
+
+    net, static, state, extras = rh.run_reference(name, steps=steps, seed=seed, replica=replica, mode=mode,
+                                                  mutate=mutate if muts else None, np_seed=np_seed, record_tf=True,
+                                                  demand_override=demand_override)
+    extras["tf"] = tf_matrix(net, extras)
+    save(case, static, state, extras, {"scenario": name, "seed": seed, "replica": replica, "mode": mode,
+                                       "np_seed": np_seed, "mutations": muts})
+    return net
+
+
+def direct_case(case, adj, params, origin_nodes, destination_nodes=(), steps=None, seed=0, replica=0, tf_nodes=None,
+                tf_values=None, mutations=None, np_seed=20261003):
+    ref = rh.load_reference()
+    np.random.seed(np_seed)
+    net = ref["network"].Network(np.array(adj), params, origin_nodes=list(origin_nodes),
+                                 destination_nodes=list(destination_nodes))
+    if tf_nodes:
+        net.update_turning_fractions_per_node(node_ids=list(tf_nodes), new_turning_fractions=np.array(tf_values))
+    muts = mutations or []
+
+    def mutate(n, t):
+        for (mt, kind, u, v, val) in muts:
+            if mt == t and kind == "back_gate_set":
+                n.links[(u, v)].back_gate_width = val
+
+    net, static, state, extras = rh.run_reference(None, steps=steps, seed=seed, replica=replica, mutate=mutate,
+                                                  record_tf=True, network=net)
+    extras["tf"] = tf_matrix(net, extras)
+    save(case, static, state, extras, {"scenario": None, "adjacency": np.array(adj).tolist(), "params": params,
+                                       "origin_nodes": list(origin_nodes), "destination_nodes": list(destination_nodes),
+                                       "tf_nodes": list(tf_nodes or []), "tf_values": np.array(tf_values if tf_values is not None else []).tolist(),
+                                       "seed": seed, "replica": replica, "mode": "philox", "np_seed": np_seed,
+                                       "mutations": muts})
+
+
+def kat_native():
+    """G1 / G1b: the reference under its own numpy RNG (yaml seed 42 reseeds the global stream)."""
+    ref = rh.load_reference()
+    out = {}
+    for tag, mutate in (("plain", False), ("gate_mutation", True)):
+        gen = ref["env"].NetworkEnvGenerator()
+        net = gen.create_network("od_flow_example")
+        for t in range(1, gen.config["params"]["simulation_steps"]):
+            net.network_loading(t)
+            if mutate and t in (100, 101, 102, 103, 104, 105, 106, 107, 108):   # examples/six_node.py:29-30
+                net.links[(3, 5)].back_gate_width -= 0.1
+        h = hashlib.sha256()
+        for key in sorted(net.links.keys()):
+            lk = net.links[key]
+            for arr in (lk.cumulative_inflow, lk.cumulative_outflow, lk.density, lk.speed, lk.sending_flow, lk.receiving_flow):
+                h.update(np.ascontiguousarray(arr).tobytes())
+        out[tag] = {
+            "sum_cum_in_499": float(sum(l.cumulative_inflow[499] for l in net.links.values())),
+            "link_1_3_cum_in_499": float(net.links[(1, 3)].cumulative_inflow[499]),
+            "link_1_3_density_499": float(net.links[(1, 3)].density[499]),
+            "link_3_5_cum_in_499": float(net.links[(3, 5)].cumulative_inflow[499]),
+            "link_3_5_density_499": float(net.links[(3, 5)].density[499]),
+            "link_3_5_back_gate_width": float(net.links[(3, 5)].back_gate_width),
+            "link_5_3_front_gate_width": float(net.links[(5, 3)].front_gate_width),
+            "demand_node1": [float(x) for x in net.nodes[1].demand],
+            "sha256": h.hexdigest(),
+        }
+    out["numpy"] = np.__version__
+    with open(os.path.join(OUT, "kat_six_node.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("kat_six_node:", {k: (v["sum_cum_in_499"], v["sha256"][:16]) for k, v in out.items() if isinstance(v, dict)})
+
+
+FORKY_ADJ = [[0, 1, 0, 0, 0], [1, 0, 1, 0, 1], [0, 1, 0, 1, 0], [0, 0, 1, 0, 0], [0, 1, 0, 0, 0]]
+FORKY_PARAMS = {
+    "unit_time": 10, "simulation_steps": 300, "assign_flows_type": "classic",
+    "default_link": {"length": 100, "width": 3, "free_flow_speed": 1.5, "k_critical": 2, "k_jam": 6, "gamma": 0,
+                     "speed_noise_std": 0.05, "fd_type": "yperman", "bi_factor": 1.2},
+    "links": {"1_2": {"length": 100, "width": 1, "free_flow_speed": 1.5, "k_critical": 2, "k_jam": 6,
+                      "speed_noise_std": 0.05, "fd_type": "yperman", "controller_type": "gate"},
+              "2_3": {"length": 50, "width": 1, "free_flow_speed": 1.5, "k_critical": 2, "k_jam": 6,
+                      "speed_noise_std": 0.05, "fd_type": "yperman"}},
+    "demand": {"origin_0": {"peak_lambda": 15, "base_lambda": 5}, "origin_4": {"peak_lambda": 15, "base_lambda": 5}},
+}
+
+
+def replica_demand(T, r, base=20.0, peak=25.0):
+    """Config #2 per-replica origin demand: Poisson around the gaussian-peaks profile, numpy Generator(1000+r)."""
+    t = np.arange(T)
+    lam = base + peak * np.exp(-(t - T / 4) ** 2 / (2 * (T / 20) ** 2)) + peak * np.exp(-(t - 3 * T / 4) ** 2 / (2 * (T / 20) ** 2))
+    return np.random.default_rng(1000 + r).poisson(lam).astype(np.float64)
+
+
+CASES = {
+    "kat": kat_native,
+    "six_node_full": lambda: scenario_case("six_node_full", "od_flow_example"),
+    "nine_full": lambda: scenario_case("nine_full", "nine_intersections"),
+    "long_corridor_full": lambda: scenario_case("long_corridor_full", "long_corridor",
+                                                mutations=[(150, "separator_set", 2, 3, 1.25), (300, "separator_set", 2, 3, 2.5)]),
+    "small_network_full": lambda: scenario_case("small_network_full", "small_network"),
+    "i45_prefix": lambda: scenario_case("i45_prefix", "45_intersections", steps=250),
+    "delft_prefix": lambda: scenario_case("delft_prefix", "delft", steps=70),
+    "melbourne_prefix": lambda: scenario_case("melbourne_prefix", "melbourne", steps=130),
+    "nine_meanfield": lambda: scenario_case("nine_meanfield", "nine_intersections", steps=200, mode="meanfield"),
+    "six_node_gate": lambda: scenario_case("six_node_gate", "od_flow_example",
+                                           mutations=[(t, "back_gate_delta", 3, 5, -0.1) for t in range(100, 109)]),
+    "forky": lambda: direct_case("forky", FORKY_ADJ, FORKY_PARAMS, [0, 4], tf_nodes=[1],
+                                 tf_values=[[1, 0, 0.5, 0.5, 0, 1]],
+                                 mutations=[(40, "back_gate_set", 1, 2, 0.0), (120, "back_gate_set", 1, 2, 1.0)]),
+}
+for _r in range(4):
+    CASES[f"nine_replica{_r}"] = (lambda r=_r: scenario_case(
+        f"nine_replica{r}", "nine_intersections", steps=160, seed=0, replica=r,
+        demand_override={0: replica_demand(500, 3 * r + 0), 8: replica_demand(500, 3 * r + 1),
+                         2: replica_demand(500, 3 * r + 2, peak=50.0)}))
+
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or list(CASES)
+    for c in todo:
+        CASES[c]()

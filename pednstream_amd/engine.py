@@ -1,0 +1,271 @@
+"""ctypes binding of the C-ABI engine library (include/pedn.h -> pednstream_amd/csrc/libpedn_hip.so).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no GPU is visible, creating an
+``Engine`` raises.  The scalar CPU restatement under oracle/ is test infrastructure and is never imported here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpedn_hip.so")
+
+PEDN_ALL = -1
+ABI_VERSION = 1
+ERROR_BITS = {1: "negative sending flow (ValueError, link.py:345-346,365-366)",
+              2: "negative flows at a node (Warning, node.py:192-194,218-219,237-238)",
+              4: "history index out of range (IndexError)",
+              8: "binomial with n < 0 (ValueError, link.py:382)",
+              16: "zero-step look-back: result depends on node iteration order in the reference"}
+
+_I32P, _F64P, _F32P = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float)
+
+
+class ModelDesc(C.Structure):
+    """Mirror of ``pedn_model_desc`` (include/pedn.h); field order and types must match the header."""
+
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_nodes", C.c_int32), ("n_links", C.c_int32), ("n_vlinks", C.c_int32), ("n_turns", C.c_int32),
+        ("n_demand", C.c_int32), ("n_od", C.c_int32),
+        ("T", C.c_int32), ("window", C.c_int32), ("dt", C.c_double),
+        ("node_kind", _I32P), ("node_slot_ptr", _I32P), ("node_turn_ptr", _I32P), ("node_demand_row", _I32P),
+        ("node_dyn", _I32P), ("slot_in_link", _I32P), ("slot_out_link", _I32P),
+        ("link_rev", _I32P), ("link_sep", _I32P), ("link_fd", _I32P), ("link_tau_sw", _I32P), ("link_fft", _I32P),
+        ("link_tt0", _F32P),
+        ("link_length", _F64P), ("link_width", _F64P), ("link_vf", _F64P), ("link_kc", _F64P), ("link_kj", _F64P),
+        ("link_gamma", _F64P), ("link_act", _F64P), ("link_bi", _F64P), ("link_noise", _F64P),
+        ("front_gate0", _F64P), ("back_gate0", _F64P), ("sep_width0", _F64P),
+        ("tf_init", _F64P), ("demand", _F64P), ("od_w", _F64P),
+        ("pf_temp", C.c_double), ("pf_alpha", C.c_double), ("pf_beta", C.c_double), ("pf_omega", C.c_double),
+        ("pf_eps", C.c_double),
+        ("n_up", C.c_int32), ("n_upod", C.c_int32), ("n_grp", C.c_int32), ("n_ent", C.c_int32), ("n_pair", C.c_int32),
+        ("node_up_ptr", _I32P), ("up_od_ptr", _I32P), ("upod_od", _I32P), ("node_grp_ptr", _I32P),
+        ("grp_ent_ptr", _I32P), ("grp_allphys", _I32P), ("ent_link", _I32P), ("ent_dist", _F64P),
+        ("turn_pair_ptr", _I32P), ("pair_ent", _I32P), ("pair_upod", _I32P),
+    ]
+
+
+_PTR_TYPES = {_I32P: np.int32, _F64P: np.float64, _F32P: np.float32}
+
+
+def build_model_desc(model: dict):
+    """dict from ``flatten_network`` -> (ModelDesc, keepalive list).  The arrays are borrowed by the struct."""
+    desc = ModelDesc()
+    keep = []
+    for name, ctype in ModelDesc._fields_:
+        if name == "abi_version":
+            desc.abi_version = ABI_VERSION
+        elif ctype in _PTR_TYPES:
+            arr = np.ascontiguousarray(model[name], dtype=_PTR_TYPES[ctype])
+            if arr.size == 0:
+                arr = np.zeros(1, dtype=_PTR_TYPES[ctype])      # never hand out NULL for an empty table
+            keep.append(arr)
+            setattr(desc, name, arr.ctypes.data_as(ctype))
+        else:
+            setattr(desc, name, model[name])
+    return desc, keep
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"HIP engine library not built: {LIB_PATH} is missing. Run `python -c 'import "
+                           f"__graft_entry__ as g; g.build()'` or `make -C pednstream_amd/csrc` (needs hipcc). "
+                           f"There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    sig = {
+        "pedn_abi_version": (C.c_int, []),
+        "pedn_last_error": (C.c_char_p, [P]),
+        "pedn_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int32,
+                                  C.POINTER(P)]),
+        "pedn_destroy": (C.c_int, [P]),
+        "pedn_set_demand": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
+        "pedn_set_od_weights": (C.c_int, [P, C.c_int32, _F64P, C.c_int32]),
+        "pedn_set_turning_fractions": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
+        "pedn_get_turning_fractions": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
+        "pedn_set_width": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
+        "pedn_set_widths": (C.c_int, [P, C.c_int32, _F64P]),
+        "pedn_step": (C.c_int, [P, C.c_int32]),
+        "pedn_run": (C.c_int, [P, C.c_int32, C.c_int32]),
+        "pedn_synchronize": (C.c_int, [P]),
+        "pedn_error_flags": (C.c_int, [P, C.POINTER(C.c_uint32)]),
+        "pedn_read": (C.c_int, [P, C.c_int32] + [C.c_int32] * 6 + [C.c_void_p]),
+        "pedn_device_ptr": (C.c_void_p, [P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+        "pedn_stream": (C.c_void_p, [P]),
+        "pedn_timer_begin": (C.c_int, [P]),
+        "pedn_timer_end": (C.c_int, [P, C.POINTER(C.c_float)]),
+        "pedn_reset": (C.c_int, [P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.pedn_abi_version() != ABI_VERSION:
+        raise RuntimeError("libpedn_hip.so ABI version mismatch")
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand",
+           "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
+           "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
+           "pedn_device_ptr", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset"]
+
+
+class ModelError(RuntimeError):
+    """A replica hit one of the reference's raise sites; ``flags`` holds the per-replica bit masks."""
+
+    def __init__(self, msg, flags):
+        super().__init__(msg)
+        self.flags = flags
+
+
+class Engine:
+    """One handle = one scenario x ``n_replicas`` on one GPU."""
+
+    def __init__(self, model: dict, n_replicas=1, replica_offset=0, seed=0, mode="philox", device=0):
+        self._lib = lib()
+        self.model = model
+        self.n_replicas = int(n_replicas)
+        self.T = int(model["T"])
+        self.n_links = int(model["n_links"])
+        self.n_all = self.n_links + int(model["n_vlinks"])
+        desc, self._keep = build_model_desc(model)
+        h = C.c_void_p()
+        rc = self._lib.pedn_create(C.byref(desc), self.n_replicas, int(replica_offset), int(seed),
+                                   {"philox": 0, "meanfield": 1}[mode], int(device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"pedn_create failed ({rc}): {self._lib.pedn_last_error(None).decode()}")
+        self._h = h
+
+    # -- helpers
+    def _ck(self, rc):
+        if rc < 0:
+            raise RuntimeError(f"pedn call failed ({rc}): {self._lib.pedn_last_error(self._h).decode()}")
+        return rc
+
+    @staticmethod
+    def _rep(replica):
+        return PEDN_ALL if replica is None else int(replica)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pedn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setters
+    def set_demand(self, node_index, values, replica=None):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._ck(self._lib.pedn_set_demand(self._h, int(node_index), self._rep(replica), v.ctypes.data_as(_F64P), len(v)))
+
+    def set_od_weights(self, od_index, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._ck(self._lib.pedn_set_od_weights(self._h, int(od_index), v.ctypes.data_as(_F64P), len(v)))
+
+    def set_turning_fractions(self, node_index, tf, replica=None):
+        tf = np.asarray(tf, dtype=np.float64)
+        if tf.ndim == 2:       # [edge_num, R] host mirror: NaN rows mean "not imposed"
+            for r in range(tf.shape[1]):
+                if not np.isnan(tf[:, r]).any():
+                    self.set_turning_fractions(node_index, tf[:, r], r)
+            return
+        v = np.ascontiguousarray(tf)
+        self._ck(self._lib.pedn_set_turning_fractions(self._h, int(node_index), self._rep(replica),
+                                                      v.ctypes.data_as(_F64P), len(v)))
+
+    def get_turning_fractions(self, node_index, replica=0):
+        a, b = self.model["node_turn_ptr"][node_index], self.model["node_turn_ptr"][node_index + 1]
+        out = np.empty(int(b - a), dtype=np.float64)
+        self._ck(self._lib.pedn_get_turning_fractions(self._h, int(node_index), int(replica), out.ctypes.data_as(_F64P), len(out)))
+        return out
+
+    def set_width(self, which, link, value, replica=None):
+        self._ck(self._lib.pedn_set_width(self._h, int(which), int(link), self._rep(replica), float(value)))
+
+    def set_widths(self, which, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.shape == (self.n_links, self.n_replicas)
+        self._ck(self._lib.pedn_set_widths(self._h, int(which), v.ctypes.data_as(_F64P)))
+
+    # -- stepping
+    def step(self, t):
+        self._ck(self._lib.pedn_step(self._h, int(t)))
+
+    def run(self, t0, t1):
+        self._ck(self._lib.pedn_run(self._h, int(t0), int(t1)))
+
+    def synchronize(self):
+        self._ck(self._lib.pedn_synchronize(self._h))
+
+    def reset(self):
+        self._ck(self._lib.pedn_reset(self._h))
+
+    def error_flags(self):
+        flags = np.zeros(self.n_replicas, dtype=np.uint32)
+        rc = self._ck(self._lib.pedn_error_flags(self._h, flags.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return rc, flags
+
+    def check_errors(self):
+        """Raise the reference's exception type for the first sticky error bit found (SURVEY 8b error conventions)."""
+        rc, flags = self.error_flags()
+        if rc == 0:
+            return
+        bad = int(np.flatnonzero(flags)[0])
+        bits = int(flags[bad])
+        msg = "; ".join(text for bit, text in ERROR_BITS.items() if bits & bit)
+        msg = f"replica {bad}: {msg}"
+        if bits & (1 | 8):
+            raise ValueError(msg)
+        if bits & 4:
+            raise IndexError(msg)
+        raise ModelError(msg, flags)
+
+    def timer_begin(self):
+        self._ck(self._lib.pedn_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_float()
+        self._ck(self._lib.pedn_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    # -- reads
+    def _dtype(self, field):
+        return np.float64 if field < 7 else np.float32
+
+    def _ncols(self, field):
+        return self.n_all if field < 4 else self.n_links
+
+    def read_block(self, field, t0, t1, link0=0, link1=None, rep0=0, rep1=None):
+        link1 = self._ncols(field) if link1 is None else link1
+        rep1 = self.n_replicas if rep1 is None else rep1
+        out = np.empty((t1 - t0, link1 - link0, rep1 - rep0), dtype=self._dtype(field))
+        self._ck(self._lib.pedn_read(self._h, int(field), int(t0), int(t1), int(link0), int(link1), int(rep0), int(rep1),
+                                     out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def read_column(self, field, link, replica=0):
+        return self.read_block(field, 0, self.T + 1, link, link + 1, replica, replica + 1).reshape(-1)
+
+    def read_element(self, field, link, replica, t):
+        return self.read_block(field, t, t + 1, link, link + 1, replica, replica + 1).reshape(-1)[0]
+
+    def device_ptr(self, field):
+        cols, stride = C.c_int64(), C.c_int64()
+        p = self._lib.pedn_device_ptr(self._h, int(field), C.byref(cols), C.byref(stride))
+        return p, cols.value, stride.value

@@ -227,7 +227,13 @@ class LinkView(BaseLinkView):
     def separator_width_data(self):
         if not self.is_separator:
             raise AttributeError("separator_width_data is only defined for separator links")
-        return self._hist("back_gate_width_data")     # Separator records its width in both arrays (link.py:451-452)
+        # A Separator records its width in both arrays (link.py:451-452); they differ only in the entries no step has
+        # written yet: width/2 here (link.py:425) versus the full width in back_gate_width_data (link.py:56).
+        rec = np.array(self._hist("back_gate_width_data"), dtype=np.float64)
+        t = self._net.current_step
+        rec[0] = self._width / 2
+        rec[t + 1:] = self._width / 2
+        return rec
 
     def get_density(self, time_step: int):
         """Shared-corridor density (link.py:190-197); a separator reports its own (link.py:427-428)."""

@@ -1,0 +1,114 @@
+"""Helpers shared by the parity tests: load a golden fixture, rebuild the same scenario with this repository's own
+host code, and drive the CPU oracle / HIP engine through the same sequence of steps and mutations."""
+import json
+import os
+
+import numpy as np
+
+from pednstream_amd import Network, NetworkEnvGenerator
+from pednstream_amd.flatten import flatten_network
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "data")
+
+F64_FIELDS = ["inflow", "outflow", "cumulative_inflow", "cumulative_outflow", "sending_flow", "receiving_flow",
+              "back_gate_width_data"]
+F32_FIELDS = ["travel_time", "avg_travel_time", "num_pedestrians", "density", "speed", "link_flow"]
+ALL_FIELDS = F64_FIELDS + F32_FIELDS
+
+
+class Golden:
+    def __init__(self, case):
+        self.case = case
+        z = np.load(os.path.join(GOLDEN, case + ".npz"), allow_pickle=False)
+        self.z = z
+        self.info = json.loads(str(z["info_json"]))
+        self.meta = json.loads(str(z["static_meta_json"]))
+        self.steps = self.info["steps_run"]          # histories are valid for t < steps
+        self.seed, self.replica, self.mode = self.info["seed"], self.info["replica"], self.info["mode"]
+        self.mutations = [tuple(m) for m in self.info.get("mutations", [])]
+
+    def state(self, name):
+        return self.z["state_" + name]
+
+    def static(self, name):
+        return self.z["static_" + name]
+
+    def demand(self):
+        return {int(k[len("static_demand_"):]): self.z[k] for k in self.z.files if k.startswith("static_demand_")}
+
+
+def build_network(g: Golden, **kw):
+    """This repository's Network for the golden's scenario, with the golden's demand arrays injected."""
+    np.random.seed(g.info["np_seed"])
+    if g.info["scenario"] is not None:
+        net = NetworkEnvGenerator(DATA).create_network(g.info["scenario"], verbose=False, **kw)
+    else:
+        net = Network(np.array(g.info["adjacency"]), g.info["params"], origin_nodes=g.info["origin_nodes"],
+                      destination_nodes=g.info["destination_nodes"], verbose=False, **kw)
+        if g.info["tf_nodes"]:
+            net.update_turning_fractions_per_node(g.info["tf_nodes"], np.array(g.info["tf_values"]))
+    for nid, arr in g.demand().items():
+        net.nodes[nid].demand = arr
+    return net
+
+
+def apply_mutation(net, mut):
+    """Apply one recorded between-step mutation through the link views (exercises the setter mirroring)."""
+    _, kind, u, v, val = mut
+    link = net.links[(u, v)]
+    if kind == "back_gate_delta":
+        link.back_gate_width = link.back_gate_width + val
+    elif kind == "back_gate_set":
+        link.back_gate_width = val
+    elif kind == "separator_set":
+        link.separator_width = val
+    else:
+        raise ValueError(kind)
+
+
+def run_oracle(g: Golden, net=None, steps=None):
+    """Run the CPU oracle over the golden's steps; returns (oracle, tf history [steps-1, n_turns])."""
+    import oracle_driver as od
+
+    net = net or build_network(g)
+    model = flatten_network(net)
+    o = od.Oracle(model, seed=g.seed, replica=g.replica, mode=g.mode)
+    for node in net.nodes.values():
+        tf = net._tf_host.get(node.index)
+        if tf is not None:
+            o.set_tf(node.index, tf[:, 0])
+    last = g.steps if steps is None else min(steps, g.steps)
+    tfh = []
+    for t in range(1, last):
+        o.step(t)
+        tfh.append(o.tf())
+        for mut in g.mutations:
+            if mut[0] == t:
+                apply_mutation(net, mut)
+                for which, code in (("front", 0), ("back", 1), ("sep", 2)):
+                    for l in range(model["n_links"]):
+                        o.set_width(code, l, net._widths[which][l, 0])
+    return o, np.array(tfh), model, net
+
+
+def compare_fields(get_field, g: Golden, n_links, last, f32_exact=True):
+    """get_field(name) -> [columns, >=last].  Returns a list of mismatch descriptions (empty = parity)."""
+    problems = []
+    for name in ALL_FIELDS:
+        mine = np.asarray(get_field(name))[:n_links, :last]
+        ref = g.state(name)[:, :last]
+        if mine.dtype != ref.dtype:
+            problems.append(f"{name}: dtype {mine.dtype} != {ref.dtype}")
+            continue
+        if name in F64_FIELDS or f32_exact:
+            bad = mine != ref
+        else:
+            bad = np.abs(mine.astype(np.float64) - ref) > 1e-6 * np.maximum(np.abs(ref), 1e-30)
+        if bad.any():
+            idx = np.argwhere(bad)
+            t0 = idx[:, 1].min()
+            l0 = idx[idx[:, 1] == t0][0][0]
+            problems.append(f"{name}: {bad.sum()} mismatches, first at t={t0} link={l0}: {mine[l0, t0]!r} vs {ref[l0, t0]!r}")
+    return problems

@@ -1,0 +1,31 @@
+"""The CPU oracle (oracle/pedn_oracle.c) pinned against the real reference: every golden captured from
+/root/reference under the injected RNG must be reproduced bit for bit on all 13 per-link arrays."""
+import numpy as np
+import pytest
+
+from golden_util import ALL_FIELDS, Golden, compare_fields, run_oracle
+
+CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full", "i45_prefix", "delft_prefix",
+         "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky", "nine_replica0", "nine_replica1",
+         "nine_replica2", "nine_replica3"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_reproduces_reference_bit_exact(case):
+    g = Golden(case)
+    o, tfh, model, net = run_oracle(g)
+    assert o.flags() == 0
+    problems = compare_fields(o.field, g, model["n_links"], g.steps)
+    assert not problems, "\n".join(problems)
+    # virtual links' flow arrays (update_links writes them too, node.py:154-161)
+    L = model["n_links"]
+    if model["n_vlinks"]:
+        for tag, off in (("vin", 0), ("vout", 1)):
+            for name in ("inflow", "outflow", "cumulative_inflow", "cumulative_outflow"):
+                mine = o.field(name)[L + off::2, :g.steps]
+                assert np.array_equal(mine, g.state(f"{tag}_{name}")[:, :g.steps]), (tag, name)
+    # turning fractions: the softmax uses exp(); the reference's exp is libm's (FMA build), ours is an independent
+    # < 1 ulp implementation, so fractions may differ in the last bits -- never more.
+    ref_tf = g.z["tf_hist"]
+    assert tfh.shape == ref_tf.shape
+    assert np.max(np.abs(tfh - ref_tf), initial=0.0) <= 4.5e-16
