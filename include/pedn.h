@@ -118,11 +118,13 @@ typedef struct pedn_model_desc {
   double pf_temp, pf_alpha, pf_beta, pf_omega, pf_eps;
   int32_t n_up, n_upod, n_grp, n_ent, n_pair;
   const int32_t* node_up_ptr;   /* [n_nodes+1] -> upstream groups of the node              (up_od_probs, :599-615) */
+  const int32_t* up_slot;       /* [n_up]      incoming slot (local index) the upstream group belongs to */
   const int32_t* up_od_ptr;     /* [n_up+1]    -> upod entries of one upstream */
   const int32_t* upod_od;       /* [n_upod]    OD row in od_w */
   const int32_t* node_grp_ptr;  /* [n_nodes+1] -> (od, up) softmax groups of the node       (turns_distances, :563) */
   const int32_t* grp_ent_ptr;   /* [n_grp+1]   -> downstream entries of one group */
   const int32_t* grp_allphys;   /* [n_grp]     1: every downstream is a physical link (f32 density branch, :581) */
+  const int32_t* grp_node;      /* [n_grp]     node index the group belongs to */
   const int32_t* ent_link;      /* [n_ent]     outgoing link of the entry, -1 = virtual     (:577-579) */
   const double* ent_dist;       /* [n_ent]     remaining distance */
   const int32_t* turn_pair_ptr; /* [n_turns+1] -> (entry, upod) products summed into one turning fraction (:668-686) */
@@ -173,8 +175,18 @@ void* pedn_stream(pedn_sim* sim);
 int pedn_timer_begin(pedn_sim* sim);
 int pedn_timer_end(pedn_sim* sim, float* ms);
 
+/* One step with every kernel bracketed by HIP events on the engine's stream (synchronises).  ms[0] = turning-probability
+ * kernel, ms[1] = node kernel, ms[2] = link kernel (0 when a kernel is not launched for this scenario). */
+int pedn_profile_step(pedn_sim* sim, int32_t t, float ms[3]);
+
 /* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */
 int pedn_reset(pedn_sim* sim);
+
+/* Diagnostic: evaluate the device-side arithmetic primitives on the GPU so that tests can compare them bit for bit
+ * with the oracle.  op 0: powf(a[i], b[i]) -> out (f32 in a/b/out as doubles); 1: exp(a[i]); 2: sqrt(a[i]);
+ * 3: a[i]/b[i] (f64); 4: (float)a[i]/(float)b[i]; 5: binomial(n=a[i], p=b[i]) keyed (seed, replica=i, link=7, t=11,
+ * site=0); 6: normal(sigma=a[i]) keyed (seed, replica=i, link=7, t=11). */
+int pedn_device_math(int32_t device, int32_t op, int32_t n, const double* a, const double* b, uint64_t seed, double* out);
 
 #ifdef __cplusplus
 }

@@ -620,6 +620,8 @@ int pedn_oracle_run(pedn_oracle* o, int t0, int t1) {
   return (int)o->flags;
 }
 
+void pedn_oracle_reseed(pedn_oracle* o, uint64_t seed, int32_t replica) { o->seed = seed; o->replica = (uint32_t)replica; }
+
 /* several independent replicas on host threads (cpu_baseline leg of bench.py) */
 int pedn_oracle_run_many(pedn_oracle** os, int n, int t0, int t1) {
   int flags = 0;

@@ -1,0 +1,1053 @@
+// pedn_hip.hip -- MI355X (gfx950) engine for PedNStream's network_loading hot path: HIP kernels + C-ABI (include/pedn.h).
+//
+// Data layout in HBM: every history field is one array [T+1][columns][RS] with the replica index
+// fastest (RS = replicas rounded up to a multiple of 64).  A wavefront therefore owns 64 consecutive replicas of ONE
+// link or node: topology and link parameters are wave-uniform (scalar loads), every history access of a wave is
+// one coalesced 256/512-byte row segment, and the data-dependent look-backs (cumulative_inflow[t+1-tau],
+// inflow[t-tau-k]) gather between rows of the same column.
+//
+// Kernels per step t (reference network.py:266-287):
+//   turn_prob_kernel  one lane per (softmax group, replica): P(down | up, od)      path_finder.py:561-589
+//   node_kernel       one wave per (node slot, 64 replicas), one block per bin of nodes with <= 8 slots in total:
+//                     sending flow of the slot's incoming link, receiving flow of its outgoing link, dynamic turning
+//                     fractions, the node's flow distribution through LDS, cumulative counts
+//                                                                                     node.py:164-221,230-242,272-300; link.py:216-416
+//   link_kernel       one lane per (corridor = link pair, replica): pedestrians, density, fundamental diagram,
+//                     travel time and its moving average                            link.py:133-188; functions.py:112-134
+//
+// Compile with -ffp-contract=off: results must match the reference bit for bit (cumulative counts) and the
+// arithmetic below spells out every binary32 / binary64 rounding point of numpy's scalar semantics.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pedn.h"
+#include "pedn_math.hpp"
+
+using namespace pedn;
+
+// ------------------------------------------------------------------------------------------------- device view
+enum { F_IN = 0, F_OUT, F_CI, F_CO, F_S, F_R, F_GATE };
+enum { G_TT = 0, G_ATT, G_N, G_K, G_V, G_LF };
+
+struct LinkP {  // static per-link parameters, wave-uniform on the device
+  double length, width, vf, kc, kj, gamma, act, bi, noise;
+  float tt0;
+  int32_t rev, sep, fd, tau_sw, fft;
+  int32_t pad[2];
+};
+
+struct DevView {
+  double* f64[7];
+  float* f32[6];
+  float* rsum;
+  double *front, *back, *sepw, *tf, *demand, *ent_p;
+  const double* od_w;
+  uint32_t* flags;
+  const LinkP* lp;
+  const int4* wave_desc;
+  const int32_t *node_kind, *node_slot_ptr, *node_turn_ptr, *node_demand_row, *node_dyn, *slot_in, *slot_out, *slot_up;
+  const int32_t *up_od_ptr, *upod_od, *grp_ent_ptr, *grp_allphys, *ent_link, *turn_pair_ptr, *pair_ent, *pair_upod;
+  const int32_t* pair_a;  // corridor list for link_kernel
+  const double* ent_dist;
+  int32_t L, Lall, T1, RS, R, W, n_grp, n_pairs_corr;
+  double dt, pf_temp, pf_alpha, pf_beta, pf_omega, pf_eps;
+  uint32_t k0, k1, replica_offset;
+  int32_t meanfield;
+};
+
+__device__ __forceinline__ size_t at(int t, int col, int cols, int RS, int r) {
+  return ((size_t)t * (size_t)cols + (size_t)col) * (size_t)RS + (size_t)r;
+}
+__device__ __forceinline__ float clip01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+__device__ __forceinline__ int wrap_idx(int i, int T1, uint32_t& fl) {
+  if (i < 0) i += T1;
+  if (i < 0 || i >= T1) { fl |= PEDN_F_INDEX; return 0; }
+  return i;
+}
+
+// Link.get_density (link.py:190-197) / Separator.get_density (:427-428) at history index t
+__device__ __forceinline__ float dens_at(const DevView& v, const LinkP& P, int l, int t, int r) {
+  if (P.sep) return v.f32[G_K][at(t, l, v.L, v.RS, r)];
+  float n = v.f32[G_N][at(t, l, v.L, v.RS, r)] + v.f32[G_N][at(t, P.rev, v.L, v.RS, r)];
+  return n / (float)(P.length * P.width);
+}
+
+// Link.cal_sending_flow (link.py:216-370) incl. get_outflow (:199-214); nself/nrev = num_pedestrians[t'] of l / reverse
+__device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, float nself, float nrev, uint32_t& fl) {
+  const int L = v.L, RS = v.RS, T1 = v.T1;
+  double* S = v.f64[F_S];
+  if (tp < P.fft) {  // link.py:267-269
+    S[at(tp, l, L, RS, r)] = 0.0;
+    return 0.0;
+  }
+  float kk = v.f32[G_K][at(tp, l, L, RS, r)];
+  float att = v.f32[G_ATT][at(tp, l, L, RS, r)];
+  double aw = P.sep ? v.sepw[(size_t)l * RS + r] : P.width;
+  float dens = P.sep ? kk : (nself + nrev) / (float)(P.length * aw);
+  int tau = __float2int_rn(att / (float)v.dt);  // link.py:260
+  if (tau <= 0) fl |= PEDN_F_SAME_STEP;
+  int idx = tp + 1 - tau;
+  if (idx < 0) idx = 0;
+  float cf = clip01((kk - (float)P.kc) / (float)(P.kj - P.kc));  // link.py:282
+  double ff = v.f64[F_CI][at(idx, l, v.Lall, RS, r)] - v.f64[F_CO][at(tp, l, v.Lall, RS, r)];
+  if (!(ff > 0.0)) ff = 0.0;
+  double bnd = (double)(cf * nself) + (double)(1.0f - cf) * ff;  // link.py:284-288
+  double smax = v.front[(size_t)l * RS + r] * P.kc * P.vf * v.dt;  // link.py:296
+  double s = smax < bnd ? smax : bnd;
+  double orig = s;
+  RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)tp, 0u};
+  if (s > 0.0) {
+    float rf = clip01(dens / (float)P.kj);                          // link.py:315
+    float p = 0.7f + (float)(0.85 - 0.7) * pedn_powf(rf, 0.8f);     // link.py:317
+    bool diffusion_used = false;
+    if (dens <= (float)P.kc) {  // link.py:323
+      float F = 1.0f / (1.0f + (float)P.gamma * att);
+      float G = 1.0f - F;
+      const double* in = v.f64[F_IN];
+      double d = (double)F * in[at(wrap_idx(tp - tau, T1, fl), l, v.Lall, RS, r)] +
+                 (double)(F * G) * in[at(wrap_idx(tp - tau - 1, T1, fl), l, v.Lall, RS, r)] +
+                 (double)(F * pedn_powf(G, 2.0f)) * in[at(wrap_idx(tp - tau - 2, T1, fl), l, v.Lall, RS, r)] +
+                 (double)(F * pedn_powf(G, 3.0f)) * in[at(wrap_idx(tp - tau - 3, T1, fl), l, v.Lall, RS, r)];
+      d = ceil(d);
+      if (d > 0.0) {  // link.py:326-330
+        double mix = 0.8 * d + (1 - 0.8) * s;
+        s = floor(mix < s ? mix : s);
+        diffusion_used = true;
+      }
+    }
+    if (!diffusion_used) {  // link.py:336-338,342-344
+      key.site = 0u;
+      s = rng_binomial((long long)floor(s), (double)p, key, v.meanfield);
+    }
+    if (s < 0.0) fl |= PEDN_F_NEG_SENDING;
+  }
+  if (P.act > 0.0 && s > 1.0) {  // link.py:351-358
+    key.site = 1u;
+    s -= rng_binomial((long long)floor(s), P.act, key, v.meanfield);
+  }
+  if (!(s > 0.0)) s = 0.0;
+  double sm = floor(0.8 * s + 0.2 * S[at(wrap_idx(tp - 1, T1, fl), l, L, RS, r)]);  // link.py:364
+  s = orig < sm ? orig : sm;
+  if (s < 0.0) fl |= PEDN_F_NEG_SENDING;
+  S[at(tp, l, L, RS, r)] = s;
+  return s;
+}
+
+// Link/Separator.cal_receiving_flow[_with_reverse] (link.py:372-416,480-512); nrev = num_pedestrians[t'] of reverse
+__device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int r, float nrev, double s_rev, uint32_t& fl) {
+  const int L = v.L, RS = v.RS, T1 = v.T1;
+  double aw = P.sep ? v.sepw[(size_t)l * RS + r] : P.width;
+  double kjA = P.kj * (P.length * aw);
+  int tsw = P.tau_sw;
+  double b;
+  if (P.sep) {
+    if (tp + 1 - tsw < 0) b = kjA;
+    else {
+      if (tsw <= 0) fl |= PEDN_F_SAME_STEP;
+      b = v.f64[F_CO][at(tp + 1 - tsw, l, v.Lall, RS, r)] + kjA - v.f64[F_CI][at(tp, l, v.Lall, RS, r)];
+    }
+  } else {
+    if (nrev < 0.0f) fl |= PEDN_F_NEG_BINOM;
+    RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)tp, 2u};
+    double rp = rng_binomial((long long)nrev, 0.9, key, v.meanfield);  // link.py:381-382
+    if (tp + 1 - tsw < 0) b = kjA - rp;
+    else {
+      if (tsw <= 0) fl |= PEDN_F_SAME_STEP;
+      b = v.f64[F_CO][at(tp + 1 - tsw, l, v.Lall, RS, r)] + kjA - rp - v.f64[F_CI][at(tp, l, v.Lall, RS, r)];
+      if (!(b > 0.0)) b = 0.0;
+    }
+  }
+  double rmax = v.back[(size_t)l * RS + r] * P.kc * P.vf * v.dt;  // link.py:393
+  double rr = rmax < b ? rmax : b;
+  if (!(rr > 0.0)) rr = 0.0;
+  double prev = v.f64[F_R][at(wrap_idx(tp - 1, T1, fl), l, L, RS, r)];
+  if (prev >= 0.0) {  // link.py:400-401
+    double sm = floor(rr * 0.8 + prev * 0.2);
+    rr = sm < rr ? sm : rr;
+  }
+  if (P.sep) return rr > 0.0 ? rr : 0.0;
+  rr = rr - s_rev;  // link.py:415-416
+  return rr > 0.0 ? rr : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------- kernels
+// P(down | up, od) for every softmax group (update_node_turn_probs, path_finder.py:561-589)
+__global__ __launch_bounds__(256) void turn_prob_kernel(DevView v, int t) {
+  const int RS = v.RS;
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int g = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
+  int r = (int)(gid % (size_t)RS);
+  if (g >= v.n_grp) return;
+  uint32_t fl = 0;
+  const int a = v.grp_ent_ptr[g], n = v.grp_ent_ptr[g + 1] - a;
+  const int allphys = v.grp_allphys[g];
+  double cap[PEDN_MAX_DEGREE - 1];
+  float kf[PEDN_MAX_DEGREE - 1];
+  double sumd = 0.0, sumc = 0.0;
+#pragma unroll
+  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
+    if (e < n) {
+      int l = v.ent_link[a + e];
+      if (l >= 0) {
+        const LinkP P = v.lp[l];
+        // density uses the live width for a separator
+        if (P.sep) kf[e] = v.f32[G_K][at(t - 1, l, v.L, RS, r)];
+        else kf[e] = dens_at(v, P, l, t - 1, r);
+        double c = v.f64[F_R][at(wrap_idx(t - 2, v.T1, fl), l, v.L, RS, r)];
+        cap[e] = c >= 0.0 ? c : v.back[(size_t)l * RS + r] * P.vf * P.kc * v.dt;  // :575-576
+      } else {
+        kf[e] = 0.0f;
+        cap[e] = 100.0;  // :577-579
+      }
+      double d = v.ent_dist[a + e];
+      sumd = (e == 0) ? d : sumd + d;
+      sumc = (e == 0) ? cap[e] : sumc + cap[e];
+    }
+  }
+  double ex[PEDN_MAX_DEGREE - 1];
+  double esum = 0.0;
+#pragma unroll
+  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
+    if (e < n) {
+      double nd;
+      if (allphys) {  // float32 array branch of :581,583
+        float x = kf[e] - 2.0f;
+        if (!(x > 0.0f)) x = 0.0f;
+        nd = (double)((float)v.pf_beta * (x / 8.0f));
+      } else {
+        double x = (double)kf[e] - 2.0;
+        if (!(x > 0.0)) x = 0.0;
+        nd = v.pf_beta * (x / 8.0);
+      }
+      double u = (v.pf_alpha * v.ent_dist[a + e]) / (sumd + 1e-6) + nd - (v.pf_omega * cap[e]) / (sumc + 1e-6) + v.pf_eps;
+      ex[e] = pedn_exp(-v.pf_temp * u);
+      esum = (e == 0) ? ex[e] : esum + ex[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e)
+    if (e < n) v.ent_p[(size_t)(a + e) * RS + r] = ex[e] / esum;
+  if (fl) atomicOr(&v.flags[r], fl);
+}
+
+// One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
+__global__ __launch_bounds__(512) void node_kernel(DevView v, int t) {
+  __shared__ double sPS[64 * 64];  // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
+  __shared__ double sR[8 * 64];    // receiving flow of each wave's outgoing link
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int RS = v.RS, L = v.L, Lall = v.Lall;
+  const int r = (int)blockIdx.y * 64 + lane;
+  const int tp = t - 1;
+  const int4 wd = v.wave_desc[(size_t)blockIdx.x * 8 + wave];
+  const int node = __builtin_amdgcn_readfirstlane(wd.x);
+  const int slot = __builtin_amdgcn_readfirstlane(wd.y);
+  const int base = __builtin_amdgcn_readfirstlane(wd.z);
+  const int m = __builtin_amdgcn_readfirstlane(wd.w);
+  const bool active = node >= 0;
+  uint32_t fl = 0;
+  double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0;
+  int lin = 0, lout = 0, kind = 0;
+
+  if (active) {
+    const int s0 = v.node_slot_ptr[node];
+    kind = v.node_kind[node];
+    lin = v.slot_in[s0 + slot];
+    lout = v.slot_out[s0 + slot];
+    if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
+      s_i = v.demand[((size_t)v.node_demand_row[node] * v.T1 + tp) * RS + r];
+      r_i = 1e6;
+    } else {
+      const LinkP Pin = v.lp[lin];
+      const LinkP Pout = v.lp[lout];
+      float n_in = v.f32[G_N][at(tp, lin, L, RS, r)];
+      float n_out = v.f32[G_N][at(tp, lout, L, RS, r)];
+      s_i = send_flow(v, Pin, lin, tp, r, n_in, n_out, fl);
+      if (s_i < 0.0) fl |= PEDN_F_NEG_FLOW;
+      r_i = recv_flow(v, Pout, lout, tp, r, n_in, s_i, fl);
+      v.f64[F_R][at(tp, lout, L, RS, r)] = r_i;  // node.py:206
+    }
+    if (s_i < 0.0 || r_i < 0.0) fl |= PEDN_F_NEG_FLOW;
+
+    if (kind == 1) {
+      // turning fractions of row `slot`: static, or recomputed from the route-choice tables (path_finder.py:591-715)
+      const int turn0 = v.node_turn_ptr[node] + slot * (m - 1);
+      double tfr[PEDN_MAX_DEGREE - 1];
+      if (v.node_dyn[node]) {
+        const int u = v.slot_up[s0 + slot];
+        double tot = 0.0;
+        int nu = 0;
+        if (u >= 0) {
+          const int qa = v.up_od_ptr[u], qb = v.up_od_ptr[u + 1];
+          nu = qb - qa;
+          for (int q = qa; q < qb; ++q) tot += v.od_w[(size_t)v.upod_od[q] * v.T1 + t];  // :599-605
+        }
+        double rowsum = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
+          if (jj < m - 1) {
+            double acc = 0.0;
+            for (int q = v.turn_pair_ptr[turn0 + jj]; q < v.turn_pair_ptr[turn0 + jj + 1]; ++q) {
+              double w = v.od_w[(size_t)v.upod_od[v.pair_upod[q]] * v.T1 + t];
+              double pod = tot > 0.0 ? w / tot : (nu > 0 ? 1.0 / (double)nu : 0.0);  // :608-615
+              acc += v.ent_p[(size_t)v.pair_ent[q] * RS + r] * pod;                    // :680-685
+            }
+            tfr[jj] = acc;
+            rowsum = (jj == 0) ? acc : rowsum + acc;
+          }
+        }
+        const bool renorm = fabs(rowsum - 1) > 1e-3;  // check_fractions, :700-714
+#pragma unroll
+        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
+          if (jj < m - 1) {
+            if (renorm) tfr[jj] = rowsum > 1e-6 ? tfr[jj] / rowsum : 1.0 / (double)(m - 1);
+            v.tf[(size_t)(turn0 + jj) * RS + r] = tfr[jj];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
+          if (jj < m - 1) tfr[jj] = v.tf[(size_t)(turn0 + jj) * RS + r];
+      }
+      // P[i][j] * s_i  (node.py:285)
+#pragma unroll
+      for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
+        if (jj < m - 1) {
+          const int j = jj < slot ? jj : jj + 1;
+          sPS[(size_t)(base + slot * m + j) * 64 + lane] = tfr[jj] * s_i;
+        }
+      }
+    } else {
+      sPS[(size_t)(base + slot) * 64 + lane] = s_i;
+    }
+    sR[wave * 64 + lane] = r_i;
+  }
+  __syncthreads();
+
+  if (active && kind == 1) {
+    // column `slot`: D_j = sum_i P[i][j] s_i (i ascending), g_ij = floor(min(P s, r_j * (P s / D_j)))  (node.py:286-298)
+    double D = 0.0;
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < PEDN_MAX_DEGREE; ++k) {
+      if (k < m && k != slot) {
+        double x = sPS[(size_t)(base + k * m + slot) * 64 + lane];
+        D = first ? x : D + x;
+        first = false;
+      }
+    }
+    const double Ds = D != 0.0 ? D : 1e-5;
+#pragma unroll
+    for (int k = 0; k < PEDN_MAX_DEGREE; ++k) {
+      if (k < m && k != slot) {
+        double a = sPS[(size_t)(base + k * m + slot) * 64 + lane];
+        double b = r_i * (a / Ds);
+        double g = floor(b < a ? b : a);
+        sPS[(size_t)(base + k * m + slot) * 64 + lane] = g;
+        qi += g;
+      }
+    }
+  }
+  __syncthreads();
+
+  if (active) {
+    if (kind == 1) {
+#pragma unroll
+      for (int j = 0; j < PEDN_MAX_DEGREE; ++j)
+        if (j < m && j != slot) qo += sPS[(size_t)(base + slot * m + j) * 64 + lane];
+      if (!(qo > 0.0)) qo = 0.0;  // np.maximum(0, flows), node.py:299
+      if (!(qi > 0.0)) qi = 0.0;
+    } else {  // OneToOneNode.solve (node.py:230-242), not floored
+      const int other = 1 - slot;
+      double s_o = sPS[(size_t)(base + other) * 64 + lane];
+      double r_o = sR[(wave - slot + other) * 64 + lane];
+      qo = s_i < r_o ? s_i : r_o;
+      qi = s_o < r_i ? s_o : r_i;
+      if (qo < 0.0 || qi < 0.0) fl |= PEDN_F_NEG_FLOW;
+    }
+    // Node.update_links (node.py:146-162; link.py:19-25)
+    v.f64[F_OUT][at(t, lin, Lall, RS, r)] = qo;
+    v.f64[F_CO][at(t, lin, Lall, RS, r)] = v.f64[F_CO][at(t - 1, lin, Lall, RS, r)] + qo;
+    v.f64[F_IN][at(t, lout, Lall, RS, r)] = qi;
+    v.f64[F_CI][at(t, lout, Lall, RS, r)] = v.f64[F_CI][at(t - 1, lout, Lall, RS, r)] + qi;
+    if (fl) atomicOr(&v.flags[r], fl);
+  }
+}
+
+// BiDirectionalFd.__call__ + the travel-time part of Link.update_speeds for one direction
+__device__ __forceinline__ void speed_update(const DevView& v, const LinkP& P, int l, int t, int r, float ks, float ko,
+                                             double live_width) {
+  const int L = v.L, RS = v.RS;
+  float ke = P.sep ? ks : ks + (float)P.bi * ko;  // functions.py:113
+  bool is64;  // true: the speed is a Python float (binary64) at this point, false: np.float32
+  double v64 = 0.0;
+  float v32 = 0.0f;
+  if (P.fd == 2 && ke <= (float)P.kc) {
+    v32 = (float)P.vf * (1.0f - ke / (float)P.kj);
+    is64 = false;
+  } else if (ke <= (float)P.kc) {
+    v64 = P.vf;
+    is64 = true;
+  } else {
+    if (P.fd == 0) v32 = (float)((P.kc * P.vf) / (P.kj - P.kc)) * ((float)P.kj / ke - 1.0f);
+    else if (P.fd == 1) v32 = ((float)(-P.vf) * (ke - (float)P.kj)) / (float)(P.kj - P.kc);
+    else v32 = (float)(P.vf * P.kc) * (1.0f / ke - (float)(1 / P.kj));
+    is64 = false;
+    if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }  // Python max(0, x) returns the int 0
+  }
+  if (P.noise > 0.0) {  // functions.py:132-133
+    double nz = 0.0;
+    if (!v.meanfield) {
+      RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)t, 3u};
+      nz = P.noise * rng_z(key);
+    }
+    if (is64) v64 = v64 + nz;
+    else v32 = v32 + (float)nz;
+  }
+  if (is64) { if (!(v64 > 0.0)) v64 = 0.0; }
+  else if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }
+  float spd = is64 ? (float)v64 : v32;
+  float tt;
+  if (is64) tt = v64 > 0.0 ? (float)(P.length / v64) : (float)(P.length / 0.05);  // link.py:177
+  else tt = (float)P.length / v32;
+  v.f32[G_V][at(t, l, L, RS, r)] = spd;
+  v.f32[G_TT][at(t, l, L, RS, r)] = tt;
+  v.f32[G_LF][at(t, l, L, RS, r)] = ks * spd;  // link.py:181
+  float rs = v.rsum[(size_t)l * RS + r] + tt;   // link.py:183-186, float32 running sum
+  if (t >= v.W) {
+    rs = rs - v.f32[G_TT][at(t - v.W, l, L, RS, r)];
+    v.f32[G_ATT][at(t, l, L, RS, r)] = rs / (float)v.W;
+  }
+  v.rsum[(size_t)l * RS + r] = rs;
+  v.f64[F_GATE][at(t, l, L, RS, r)] = live_width;  // link.py:188 / :451-452
+}
+
+// Network.update_link_states (network.py:257-264): both directions of one corridor per lane
+__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) {
+  const int RS = v.RS, L = v.L, Lall = v.Lall;
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
+  int r = (int)(gid % (size_t)RS);
+  if (p >= v.n_pairs_corr) return;
+  const int a = v.pair_a[p];
+  const LinkP Pa = v.lp[a];
+  const int b = Pa.rev;
+  const LinkP Pb = v.lp[b];
+  // link.py:133-136
+  double da = v.f64[F_IN][at(t, a, Lall, RS, r)] - v.f64[F_OUT][at(t, a, Lall, RS, r)];
+  double db = v.f64[F_IN][at(t, b, Lall, RS, r)] - v.f64[F_OUT][at(t, b, Lall, RS, r)];
+  float na = (float)((double)v.f32[G_N][at(t - 1, a, L, RS, r)] + da);
+  float nb = (float)((double)v.f32[G_N][at(t - 1, b, L, RS, r)] + db);
+  double wa = Pa.sep ? v.sepw[(size_t)a * RS + r] : Pa.width;
+  double wb = Pb.sep ? v.sepw[(size_t)b * RS + r] : Pb.width;
+  float ka = na / (float)(Pa.length * wa);
+  float kb = nb / (float)(Pb.length * wb);
+  v.f32[G_N][at(t, a, L, RS, r)] = na;
+  v.f32[G_N][at(t, b, L, RS, r)] = nb;
+  v.f32[G_K][at(t, a, L, RS, r)] = ka;
+  v.f32[G_K][at(t, b, L, RS, r)] = kb;
+  speed_update(v, Pa, a, t, r, ka, kb, Pa.sep ? wa : v.back[(size_t)a * RS + r]);
+  speed_update(v, Pb, b, t, r, kb, ka, Pb.sep ? wb : v.back[(size_t)b * RS + r]);
+}
+
+// ---- state initialisation / host <-> device helpers ---------------------------------------------------------
+__global__ void init_state_kernel(DevView v) {
+  const int RS = v.RS, L = v.L, T1 = v.T1;
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)T1 * L * RS;
+  if (gid >= total) return;
+  int r = (int)(gid % RS);
+  int l = (int)((gid / RS) % L);
+  int t = (int)(gid / ((size_t)RS * L));
+  const LinkP P = v.lp[l];
+  v.f64[F_S][gid] = -1.0;
+  v.f64[F_R][gid] = -1.0;
+  v.f64[F_GATE][gid] = P.width;  // link.py:56
+  v.f32[G_TT][gid] = t == 0 ? P.tt0 : 0.0f;
+  v.f32[G_ATT][gid] = t < v.W ? P.tt0 : 0.0f;  // link.py:91
+  v.f32[G_N][gid] = 0.0f;
+  v.f32[G_K][gid] = 0.0f;
+  v.f32[G_V][gid] = 0.0f;
+  v.f32[G_LF][gid] = 0.0f;
+  if (t == 0) v.rsum[(size_t)l * RS + r] = P.tt0;  // link.py:84
+}
+
+template <typename T>
+__global__ void gather_kernel(const T* src, T* dst, int t0, int nt, int c0, int nc, int r0, int nr, int cols, int RS) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)nt * nc * nr;
+  if (gid >= total) return;
+  int r = (int)(gid % nr);
+  int c = (int)((gid / nr) % nc);
+  int t = (int)(gid / ((size_t)nr * nc));
+  dst[gid] = src[((size_t)(t0 + t) * cols + (c0 + c)) * RS + (r0 + r)];
+}
+
+// dst[(row0 + i) * RS + r] = src[i * src_stride + (per_replica ? r : 0)] for r in [r0, r1)
+__global__ void scatter_rows_kernel(double* dst, const double* src, int n_rows, size_t row0, size_t row_stride, int RS, int r0,
+                                    int r1, int per_replica, int src_stride) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int nr = r1 - r0;
+  if (gid >= (size_t)n_rows * nr) return;
+  int i = (int)(gid / nr);
+  int r = r0 + (int)(gid % nr);
+  dst[(row0 + (size_t)i * row_stride) * RS + r] = src[(size_t)i * src_stride + (per_replica ? r : 0)];
+}
+
+__global__ void device_math_kernel(int op, int n, const double* a, const double* b, uint32_t k0, uint32_t k1, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double x = a[i], y = b ? b[i] : 0.0;
+  RngKey key{k0, k1, (uint32_t)i, 7u, 11u, 0u};
+  switch (op) {
+    case 0: out[i] = (double)pedn_powf((float)x, (float)y); break;
+    case 1: out[i] = pedn_exp(x); break;
+    case 2: out[i] = sqrt(x); break;
+    case 3: out[i] = x / y; break;
+    case 4: out[i] = (double)((float)x / (float)y); break;
+    case 5: out[i] = rng_binomial((long long)x, y, key, 0); break;
+    case 6: key.site = 3u; out[i] = x * rng_z(key); break;
+    default: out[i] = 0.0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+static thread_local std::string g_last_error;
+
+struct pedn_sim {
+  DevView v{};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int device = 0;
+  int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
+  std::vector<int32_t> node_turn_ptr, node_demand_row;
+  std::vector<void*> allocs;
+  void* stage = nullptr;
+  size_t stage_bytes = 0;
+  std::string err;
+};
+
+static int fail(pedn_sim* s, int code, const std::string& msg) {
+  g_last_error = msg;
+  if (s) s->err = msg;
+  return code;
+}
+
+#define HIP_TRY(sim, expr)                                                                     \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(sim, PEDN_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+  } while (0)
+
+template <typename T>
+static int upload(pedn_sim* s, const T* src, size_t n, const T** dst) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  HIP_TRY(s, hipMalloc(&p, bytes));
+  s->allocs.push_back(p);
+  if (n) HIP_TRY(s, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  *dst = (const T*)p;
+  return PEDN_OK;
+}
+
+template <typename T>
+static int dalloc(pedn_sim* s, size_t n, T** dst) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+  if (e != hipSuccess) return fail(s, PEDN_E_NOMEM, std::string("hipMalloc of ") + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e));
+  s->allocs.push_back(p);
+  *dst = (T*)p;
+  return PEDN_OK;
+}
+
+static int ensure_stage(pedn_sim* s, size_t bytes) {
+  if (bytes <= s->stage_bytes) return PEDN_OK;
+  if (s->stage) HIP_TRY(s, hipFree(s->stage));
+  s->stage = nullptr;
+  s->stage_bytes = 0;
+  size_t want = std::max<size_t>(bytes, 1 << 20);
+  HIP_TRY(s, hipMalloc(&s->stage, want));
+  s->stage_bytes = want;
+  return PEDN_OK;
+}
+
+static int reset_state(pedn_sim* s) {
+  DevView& v = s->v;
+  size_t n_all = (size_t)v.T1 * v.Lall * v.RS, n_l = (size_t)v.T1 * v.L * v.RS;
+  for (int f = 0; f < 4; ++f) HIP_TRY(s, hipMemsetAsync(v.f64[f], 0, n_all * sizeof(double), s->stream));
+  HIP_TRY(s, hipMemsetAsync(v.flags, 0, (size_t)v.RS * sizeof(uint32_t), s->stream));
+  if (v.L > 0) {
+    unsigned blocks = (unsigned)((n_l + 255) / 256);
+    hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s->stream, v);
+    HIP_TRY(s, hipGetLastError());
+  }
+  return PEDN_OK;
+}
+
+extern "C" {
+
+int pedn_abi_version(void) { return PEDN_ABI_VERSION; }
+
+const char* pedn_last_error(const pedn_sim* sim) { return sim ? sim->err.c_str() : g_last_error.c_str(); }
+
+int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_offset, uint64_t seed, int32_t rng_mode,
+                int32_t device, pedn_sim** out) {
+  if (!m || !out) return fail(nullptr, PEDN_E_ARG, "null argument");
+  *out = nullptr;
+  if (m->abi_version != PEDN_ABI_VERSION) return fail(nullptr, PEDN_E_ARG, "pedn_model_desc.abi_version mismatch");
+  if (n_replicas < 1 || m->n_nodes < 1 || m->n_links < 0 || m->T < 2 || m->window < 1)
+    return fail(nullptr, PEDN_E_ARG, "bad sizes in model description");
+  const int N = m->n_nodes, L = m->n_links;
+  const int n_slots = m->node_slot_ptr[N];
+  // ---- validate topology against what the kernels assume
+  for (int n = 0; n < N; ++n) {
+    int deg = m->node_slot_ptr[n + 1] - m->node_slot_ptr[n];
+    if (deg < 2 || deg > PEDN_MAX_DEGREE)
+      return fail(nullptr, PEDN_E_ARG, "node degree " + std::to_string(deg) + " outside 2.." + std::to_string(PEDN_MAX_DEGREE));
+    if (m->node_kind[n] == 0 && deg != 2) return fail(nullptr, PEDN_E_ARG, "one-to-one node with degree != 2");
+    if (m->node_turn_ptr[n + 1] - m->node_turn_ptr[n] != deg * (deg - 1)) return fail(nullptr, PEDN_E_ARG, "node_turn_ptr inconsistent");
+    for (int k = m->node_slot_ptr[n]; k < m->node_slot_ptr[n + 1]; ++k) {
+      int li = m->slot_in_link[k], lo = m->slot_out_link[k];
+      if (li < 0 || lo < 0 || li >= L + m->n_vlinks || lo >= L + m->n_vlinks) return fail(nullptr, PEDN_E_ARG, "slot link index out of range");
+      if ((li >= L) != (lo >= L)) return fail(nullptr, PEDN_E_ARG, "virtual/physical mismatch in a slot");
+      if (li < L && m->link_rev[li] != lo) return fail(nullptr, PEDN_E_ARG, "slot does not hold a reverse pair");
+      if (li >= L && (m->node_demand_row[n] < 0 || m->node_demand_row[n] >= m->n_demand)) return fail(nullptr, PEDN_E_ARG, "virtual slot without demand row");
+    }
+  }
+  for (int l = 0; l < L; ++l) {
+    int rv = m->link_rev[l];
+    if (rv < 0 || rv >= L || rv == l || m->link_rev[rv] != l) return fail(nullptr, PEDN_E_ARG, "link_rev is not an involution");
+    if (m->link_fd[l] < 0 || m->link_fd[l] > 2) return fail(nullptr, PEDN_E_ARG, "unknown fundamental diagram type");
+  }
+  for (int g = 0; g < m->n_grp; ++g)
+    if (m->grp_ent_ptr[g + 1] - m->grp_ent_ptr[g] > PEDN_MAX_DEGREE - 1) return fail(nullptr, PEDN_E_ARG, "softmax group too large");
+
+  HIP_TRY(nullptr, hipSetDevice(device));
+  pedn_sim* s = new pedn_sim();
+  s->device = device;
+  DevView& v = s->v;
+  v.L = L;
+  v.Lall = L + m->n_vlinks;
+  v.T1 = m->T + 1;
+  v.R = n_replicas;
+  v.RS = (n_replicas + 63) / 64 * 64;
+  v.W = m->window;
+  v.dt = m->dt;
+  v.pf_temp = m->pf_temp; v.pf_alpha = m->pf_alpha; v.pf_beta = m->pf_beta; v.pf_omega = m->pf_omega; v.pf_eps = m->pf_eps;
+  v.k0 = (uint32_t)seed; v.k1 = (uint32_t)(seed >> 32);
+  v.replica_offset = (uint32_t)replica_offset;
+  v.meanfield = rng_mode == PEDN_RNG_MEANFIELD;
+  v.n_grp = m->n_grp;
+  s->n_nodes = N; s->n_turns = m->n_turns; s->n_demand = m->n_demand; s->n_od = m->n_od; s->n_ent = m->n_ent;
+  s->node_turn_ptr.assign(m->node_turn_ptr, m->node_turn_ptr + N + 1);
+  s->node_demand_row.assign(m->node_demand_row, m->node_demand_row + N);
+
+#define TRY(expr) do { int _rc = (expr); if (_rc != PEDN_OK) { std::string keep = g_last_error; pedn_destroy(s); g_last_error = keep; return _rc; } } while (0)
+  {
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; return fail(nullptr, PEDN_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    hipEventCreate(&s->ev0);
+    hipEventCreate(&s->ev1);
+  }
+  // ---- memory budget
+  {
+    size_t RS = v.RS, T1 = v.T1;
+    size_t need = 4 * T1 * v.Lall * RS * 8 + 3 * T1 * (size_t)L * RS * 8 + 6 * T1 * (size_t)L * RS * 4 + (size_t)m->n_demand * T1 * RS * 8 +
+                  (size_t)(m->n_turns + m->n_ent + 3 * L) * RS * 8;
+    size_t free_b = 0, total_b = 0;
+    hipMemGetInfo(&free_b, &total_b);
+    if (need + (256u << 20) > free_b) {
+      std::string msg = "not enough HBM: need " + std::to_string(need >> 20) + " MiB, free " + std::to_string(free_b >> 20) + " MiB";
+      pedn_destroy(s);
+      return fail(nullptr, PEDN_E_NOMEM, msg);
+    }
+  }
+  // ---- static tables
+  std::vector<LinkP> lp(std::max(L, 1));
+  for (int l = 0; l < L; ++l) {
+    LinkP& P = lp[l];
+    P.length = m->link_length[l]; P.width = m->link_width[l]; P.vf = m->link_vf[l]; P.kc = m->link_kc[l]; P.kj = m->link_kj[l];
+    P.gamma = m->link_gamma[l]; P.act = m->link_act[l]; P.bi = m->link_bi[l]; P.noise = m->link_noise[l];
+    P.tt0 = m->link_tt0[l]; P.rev = m->link_rev[l]; P.sep = m->link_sep[l]; P.fd = m->link_fd[l];
+    P.tau_sw = m->link_tau_sw[l]; P.fft = m->link_fft[l]; P.pad[0] = P.pad[1] = 0;
+  }
+  TRY(upload(s, lp.data(), lp.size(), &v.lp));
+  TRY(upload(s, m->node_kind, N, &v.node_kind));
+  TRY(upload(s, m->node_slot_ptr, N + 1, &v.node_slot_ptr));
+  TRY(upload(s, m->node_turn_ptr, N + 1, &v.node_turn_ptr));
+  TRY(upload(s, m->node_demand_row, N, &v.node_demand_row));
+  TRY(upload(s, m->node_dyn, N, &v.node_dyn));
+  TRY(upload(s, m->slot_in_link, n_slots, &v.slot_in));
+  TRY(upload(s, m->slot_out_link, n_slots, &v.slot_out));
+  {
+    std::vector<int32_t> slot_up(n_slots, -1);
+    for (int n = 0; n < N; ++n)
+      for (int u = m->node_up_ptr[n]; u < m->node_up_ptr[n + 1]; ++u) slot_up[m->node_slot_ptr[n] + m->up_slot[u]] = u;
+    TRY(upload(s, slot_up.data(), slot_up.size(), &v.slot_up));
+  }
+  TRY(upload(s, m->up_od_ptr, m->n_up + 1, &v.up_od_ptr));
+  TRY(upload(s, m->upod_od, m->n_upod, &v.upod_od));
+  TRY(upload(s, m->grp_ent_ptr, m->n_grp + 1, &v.grp_ent_ptr));
+  TRY(upload(s, m->grp_allphys, m->n_grp, &v.grp_allphys));
+  TRY(upload(s, m->ent_link, m->n_ent, &v.ent_link));
+  TRY(upload(s, m->ent_dist, m->n_ent, &v.ent_dist));
+  TRY(upload(s, m->turn_pair_ptr, m->n_turns + 1, &v.turn_pair_ptr));
+  TRY(upload(s, m->pair_ent, m->n_pair, &v.pair_ent));
+  TRY(upload(s, m->pair_upod, m->n_pair, &v.pair_upod));
+  TRY(upload(s, m->od_w, (size_t)m->n_od * v.T1, &v.od_w));
+  {  // corridors: one lane of link_kernel updates both directions
+    std::vector<int32_t> pa;
+    for (int l = 0; l < L; ++l)
+      if (l < m->link_rev[l]) pa.push_back(l);
+    v.n_pairs_corr = (int)pa.size();
+    TRY(upload(s, pa.data(), pa.size(), &v.pair_a));
+  }
+  {  // bin nodes into blocks of 8 waves (first-fit decreasing on the slot count)
+    std::vector<int> order(N);
+    for (int n = 0; n < N; ++n) order[n] = n;
+    auto deg = [&](int n) { return m->node_slot_ptr[n + 1] - m->node_slot_ptr[n]; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return deg(a) > deg(b); });
+    std::vector<std::vector<int>> bins;
+    std::vector<int> fill;
+    for (int n : order) {
+      int d = deg(n), chosen = -1;
+      for (size_t b = 0; b < bins.size(); ++b)
+        if (fill[b] + d <= 8) { chosen = (int)b; break; }
+      if (chosen < 0) { bins.emplace_back(); fill.push_back(0); chosen = (int)bins.size() - 1; }
+      bins[chosen].push_back(n);
+      fill[chosen] += d;
+    }
+    std::vector<int4> wd(bins.size() * 8, make_int4(-1, 0, 0, 0));
+    for (size_t b = 0; b < bins.size(); ++b) {
+      int wave = 0, base = 0;
+      for (int n : bins[b]) {
+        int d = deg(n);
+        for (int k = 0; k < d; ++k) wd[b * 8 + wave++] = make_int4(n, k, base, d);
+        base += d * d;  // <= 64 tiles because sum(d) <= 8
+      }
+    }
+    s->n_blocks = (int)bins.size();
+    TRY(upload(s, wd.data(), wd.size(), &v.wave_desc));
+  }
+  // ---- dynamic state
+  {
+    size_t RS = v.RS, T1 = v.T1;
+    for (int f = 0; f < 4; ++f) TRY(dalloc(s, T1 * v.Lall * RS, &v.f64[f]));
+    for (int f = 4; f < 7; ++f) TRY(dalloc(s, T1 * (size_t)L * RS, &v.f64[f]));
+    for (int f = 0; f < 6; ++f) TRY(dalloc(s, T1 * (size_t)L * RS, &v.f32[f]));
+    TRY(dalloc(s, (size_t)L * RS, &v.rsum));
+    TRY(dalloc(s, (size_t)L * RS, &v.front));
+    TRY(dalloc(s, (size_t)L * RS, &v.back));
+    TRY(dalloc(s, (size_t)L * RS, &v.sepw));
+    TRY(dalloc(s, (size_t)m->n_turns * RS, &v.tf));
+    TRY(dalloc(s, (size_t)m->n_demand * T1 * RS, &v.demand));
+    TRY(dalloc(s, (size_t)m->n_ent * RS, &v.ent_p));
+    TRY(dalloc(s, RS, &v.flags));
+  }
+  // initial widths, turning fractions, demand (broadcast to every replica)
+  {
+    const double* w0[3] = {m->front_gate0, m->back_gate0, m->sep_width0};
+    double* dst[3] = {v.front, v.back, v.sepw};
+    for (int k = 0; k < 3; ++k) {
+      if (L == 0) break;
+      TRY(ensure_stage(s, (size_t)L * 8));
+      HIP_TRY(s, hipMemcpyAsync(s->stage, w0[k], (size_t)L * 8, hipMemcpyHostToDevice, s->stream));
+      size_t n = (size_t)L * v.RS;
+      hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst[k], (const double*)s->stage, L,
+                         (size_t)0, (size_t)1, v.RS, 0, v.RS, 0, 1);
+      HIP_TRY(s, hipStreamSynchronize(s->stream));
+    }
+    if (m->n_turns) {
+      TRY(ensure_stage(s, (size_t)m->n_turns * 8));
+      HIP_TRY(s, hipMemcpyAsync(s->stage, m->tf_init, (size_t)m->n_turns * 8, hipMemcpyHostToDevice, s->stream));
+      size_t n = (size_t)m->n_turns * v.RS;
+      hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v.tf, (const double*)s->stage,
+                         m->n_turns, (size_t)0, (size_t)1, v.RS, 0, v.RS, 0, 1);
+      HIP_TRY(s, hipStreamSynchronize(s->stream));
+    }
+    if (m->n_demand) {
+      size_t rows = (size_t)m->n_demand * v.T1;
+      TRY(ensure_stage(s, rows * 8));
+      HIP_TRY(s, hipMemcpyAsync(s->stage, m->demand, rows * 8, hipMemcpyHostToDevice, s->stream));
+      size_t n = rows * v.RS;
+      hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v.demand, (const double*)s->stage,
+                         (int)rows, (size_t)0, (size_t)1, v.RS, 0, v.RS, 0, 1);
+      HIP_TRY(s, hipStreamSynchronize(s->stream));
+    }
+    if (m->n_ent) HIP_TRY(s, hipMemsetAsync(v.ent_p, 0, (size_t)m->n_ent * v.RS * 8, s->stream));
+  }
+  {
+    int rc = reset_state(s);
+    if (rc != PEDN_OK) { std::string keep = g_last_error; pedn_destroy(s); g_last_error = keep; return rc; }
+  }
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+#undef TRY
+  *out = s;
+  return PEDN_OK;
+}
+
+int pedn_destroy(pedn_sim* s) {
+  if (!s) return PEDN_OK;
+  hipSetDevice(s->device);
+  if (s->stream) hipStreamSynchronize(s->stream);
+  for (void* p : s->allocs) hipFree(p);
+  if (s->stage) hipFree(s->stage);
+  if (s->ev0) hipEventDestroy(s->ev0);
+  if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->stream) hipStreamDestroy(s->stream);
+  delete s;
+  return PEDN_OK;
+}
+
+int pedn_reset(pedn_sim* s) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  HIP_TRY(s, hipSetDevice(s->device));
+  return reset_state(s);
+}
+
+// values (host) -> rows of a [rows][RS] device array, one replica or all
+static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows, size_t row0, size_t row_stride, int replica) {
+  if (n_rows <= 0) return PEDN_OK;
+  DevView& v = s->v;
+  if (replica != PEDN_ALL && (replica < 0 || replica >= v.R)) return fail(s, PEDN_E_ARG, "replica out of range");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));  // the staging buffer may still be read by an earlier scatter
+  int rc = ensure_stage(s, (size_t)n_rows * 8);
+  if (rc != PEDN_OK) return rc;
+  HIP_TRY(s, hipMemcpyAsync(s->stage, values, (size_t)n_rows * 8, hipMemcpyHostToDevice, s->stream));
+  int r0 = replica == PEDN_ALL ? 0 : replica, r1 = replica == PEDN_ALL ? v.RS : replica + 1;
+  size_t n = (size_t)n_rows * (r1 - r0);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst, (const double*)s->stage, n_rows,
+                     row0, row_stride, v.RS, r0, r1, 0, 1);
+  HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
+int pedn_set_demand(pedn_sim* s, int32_t node, int32_t replica, const double* values, int32_t n) {
+  if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
+  if (node < 0 || node >= s->n_nodes) return fail(s, PEDN_E_ARG, "node out of range");
+  int row = s->node_demand_row[node];
+  if (row < 0) return fail(s, PEDN_E_ARG, "node has no virtual (origin/destination) link");
+  std::vector<double> full(s->v.T1, 0.0);
+  for (int i = 0; i < n && i < s->v.T1; ++i) full[i] = values[i];
+  return push_rows(s, s->v.demand, full.data(), s->v.T1, (size_t)row * s->v.T1, 1, replica);
+}
+
+int pedn_set_od_weights(pedn_sim* s, int32_t od, const double* values, int32_t n) {
+  if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
+  if (od < 0 || od >= s->n_od || n != s->v.T1) return fail(s, PEDN_E_ARG, "od index or length out of range");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipMemcpy((void*)(s->v.od_w + (size_t)od * s->v.T1), values, (size_t)n * 8, hipMemcpyHostToDevice));
+  return PEDN_OK;
+}
+
+int pedn_set_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, const double* tf, int32_t n) {
+  if (!s || !tf) return fail(s, PEDN_E_ARG, "null argument");
+  if (node < 0 || node >= s->n_nodes) return fail(s, PEDN_E_ARG, "node out of range");
+  int a = s->node_turn_ptr[node], b = s->node_turn_ptr[node + 1];
+  if (n != b - a) return fail(s, PEDN_E_ARG, "turning-fraction count does not match m(m-1)");
+  return push_rows(s, s->v.tf, tf, n, (size_t)a, 1, replica);
+}
+
+int pedn_get_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, double* tf, int32_t n) {
+  if (!s || !tf) return fail(s, PEDN_E_ARG, "null argument");
+  if (node < 0 || node >= s->n_nodes) return fail(s, PEDN_E_ARG, "node out of range");
+  if (replica < 0 || replica >= s->v.R) return fail(s, PEDN_E_ARG, "replica out of range");
+  int a = s->node_turn_ptr[node], b = s->node_turn_ptr[node + 1];
+  if (n != b - a) return fail(s, PEDN_E_ARG, "turning-fraction count does not match m(m-1)");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipMemcpy2D(tf, 8, s->v.tf + (size_t)a * s->v.RS + replica, (size_t)s->v.RS * 8, 8, n, hipMemcpyDeviceToHost));
+  return PEDN_OK;
+}
+
+int pedn_set_width(pedn_sim* s, int32_t which, int32_t link, int32_t replica, double value) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (link < 0 || link >= s->v.L || which < 0 || which > 2) return fail(s, PEDN_E_ARG, "link or selector out of range");
+  double* dst = which == PEDN_W_FRONT ? s->v.front : which == PEDN_W_BACK ? s->v.back : s->v.sepw;
+  return push_rows(s, dst, &value, 1, (size_t)link, 1, replica);
+}
+
+int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
+  if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
+  if (which < 0 || which > 2) return fail(s, PEDN_E_ARG, "selector out of range");
+  DevView& v = s->v;
+  if (v.L == 0) return PEDN_OK;
+  double* dst = which == PEDN_W_FRONT ? v.front : which == PEDN_W_BACK ? v.back : v.sepw;
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  size_t bytes = (size_t)v.L * v.R * 8;
+  int rc = ensure_stage(s, bytes);
+  if (rc != PEDN_OK) return rc;
+  HIP_TRY(s, hipMemcpyAsync(s->stage, values, bytes, hipMemcpyHostToDevice, s->stream));
+  size_t n = (size_t)v.L * v.R;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst, (const double*)s->stage, v.L,
+                     (size_t)0, (size_t)1, v.RS, 0, v.R, 1, v.R);
+  HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
+static int launch_step(pedn_sim* s, int t) {
+  DevView& v = s->v;
+  const unsigned rgroups = (unsigned)(v.RS / 64);
+  if (v.n_grp > 0) {
+    size_t n = (size_t)v.n_grp * v.RS;
+    hipLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+  }
+  hipLaunchKernelGGL(node_kernel, dim3((unsigned)s->n_blocks, rgroups), dim3(512), 0, s->stream, v, t);
+  if (v.n_pairs_corr > 0) {
+    size_t n = (size_t)v.n_pairs_corr * v.RS;
+    hipLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+  }
+  return PEDN_OK;
+}
+
+int pedn_step(pedn_sim* s, int32_t t) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
+  HIP_TRY(s, hipSetDevice(s->device));
+  launch_step(s, t);
+  HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
+int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
+  if (!s || !ms) return fail(s, PEDN_E_ARG, "null argument");
+  if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
+  HIP_TRY(s, hipSetDevice(s->device));
+  DevView& v = s->v;
+  hipEvent_t ev[4];
+  for (int i = 0; i < 4; ++i) HIP_TRY(s, hipEventCreate(&ev[i]));
+  const unsigned rgroups = (unsigned)(v.RS / 64);
+  HIP_TRY(s, hipEventRecord(ev[0], s->stream));
+  if (v.n_grp > 0) {
+    size_t n = (size_t)v.n_grp * v.RS;
+    hipLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+  }
+  HIP_TRY(s, hipEventRecord(ev[1], s->stream));
+  hipLaunchKernelGGL(node_kernel, dim3((unsigned)s->n_blocks, rgroups), dim3(512), 0, s->stream, v, t);
+  HIP_TRY(s, hipEventRecord(ev[2], s->stream));
+  if (v.n_pairs_corr > 0) {
+    size_t n = (size_t)v.n_pairs_corr * v.RS;
+    hipLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+  }
+  HIP_TRY(s, hipEventRecord(ev[3], s->stream));
+  HIP_TRY(s, hipEventSynchronize(ev[3]));
+  HIP_TRY(s, hipGetLastError());
+  for (int i = 0; i < 3; ++i) HIP_TRY(s, hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+  if (v.n_grp == 0) ms[0] = 0.0f;
+  for (int i = 0; i < 4; ++i) hipEventDestroy(ev[i]);
+  return PEDN_OK;
+}
+
+int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (t0 < 1 || t1 > s->v.T1 || t0 > t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
+  HIP_TRY(s, hipSetDevice(s->device));
+  for (int t = t0; t < t1; ++t) launch_step(s, t);
+  HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
+int pedn_synchronize(pedn_sim* s) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return PEDN_OK;
+}
+
+int pedn_error_flags(pedn_sim* s, uint32_t* flags) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  std::vector<uint32_t> h(s->v.RS);
+  HIP_TRY(s, hipMemcpy(h.data(), s->v.flags, (size_t)s->v.RS * 4, hipMemcpyDeviceToHost));
+  uint32_t any = 0;
+  for (int r = 0; r < s->v.R; ++r) {
+    any |= h[r];
+    if (flags) flags[r] = h[r];
+  }
+  return (int)any;
+}
+
+int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, int32_t c1, int32_t r0, int32_t r1, void* out) {
+  if (!s || !out) return fail(s, PEDN_E_ARG, "null argument");
+  DevView& v = s->v;
+  if (field < 0 || field >= PEDN_N_FIELDS) return fail(s, PEDN_E_ARG, "unknown field");
+  int cols = field < 4 ? v.Lall : v.L;
+  if (t0 < 0 || t1 > v.T1 || t0 >= t1 || c0 < 0 || c1 > cols || c0 >= c1 || r0 < 0 || r1 > v.R || r0 >= r1)
+    return fail(s, PEDN_E_ARG, "read range out of bounds");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  size_t n = (size_t)(t1 - t0) * (c1 - c0) * (r1 - r0);
+  size_t esz = field < 7 ? 8 : 4;
+  int rc = ensure_stage(s, n * esz);
+  if (rc != PEDN_OK) return rc;
+  unsigned blocks = (unsigned)((n + 255) / 256);
+  if (field < 7)
+    hipLaunchKernelGGL(gather_kernel<double>, dim3(blocks), dim3(256), 0, s->stream, (const double*)v.f64[field], (double*)s->stage, t0,
+                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS);
+  else
+    hipLaunchKernelGGL(gather_kernel<float>, dim3(blocks), dim3(256), 0, s->stream, (const float*)v.f32[field - 7], (float*)s->stage, t0,
+                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS);
+  HIP_TRY(s, hipGetLastError());
+  HIP_TRY(s, hipMemcpyAsync(out, s->stage, n * esz, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return PEDN_OK;
+}
+
+void* pedn_device_ptr(pedn_sim* s, int32_t field, int64_t* columns, int64_t* replica_stride) {
+  if (!s || field < 0 || field >= PEDN_N_FIELDS) return nullptr;
+  if (columns) *columns = field < 4 ? s->v.Lall : s->v.L;
+  if (replica_stride) *replica_stride = s->v.RS;
+  return field < 7 ? (void*)s->v.f64[field] : (void*)s->v.f32[field - 7];
+}
+
+void* pedn_stream(pedn_sim* s) { return s ? (void*)s->stream : nullptr; }
+
+int pedn_timer_begin(pedn_sim* s) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipEventRecord(s->ev0, s->stream));
+  return PEDN_OK;
+}
+
+int pedn_timer_end(pedn_sim* s, float* ms) {
+  if (!s || !ms) return fail(s, PEDN_E_ARG, "null argument");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipEventRecord(s->ev1, s->stream));
+  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return PEDN_OK;
+}
+
+int pedn_device_math(int32_t device, int32_t op, int32_t n, const double* a, const double* b, uint64_t seed, double* out) {
+  if (n <= 0 || !a || !out) return fail(nullptr, PEDN_E_ARG, "bad argument");
+  HIP_TRY(nullptr, hipSetDevice(device));
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIP_TRY(nullptr, hipMalloc((void**)&da, (size_t)n * 8));
+  HIP_TRY(nullptr, hipMalloc((void**)&dout, (size_t)n * 8));
+  HIP_TRY(nullptr, hipMemcpy(da, a, (size_t)n * 8, hipMemcpyHostToDevice));
+  if (b) {
+    HIP_TRY(nullptr, hipMalloc((void**)&db, (size_t)n * 8));
+    HIP_TRY(nullptr, hipMemcpy(db, b, (size_t)n * 8, hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(device_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, n, (const double*)da, (const double*)db,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), dout);
+  HIP_TRY(nullptr, hipDeviceSynchronize());
+  HIP_TRY(nullptr, hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
+  hipFree(da);
+  hipFree(dout);
+  if (db) hipFree(db);
+  return PEDN_OK;
+}
+
+}  // extern "C"

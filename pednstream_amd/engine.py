@@ -41,8 +41,8 @@ class ModelDesc(C.Structure):
         ("pf_temp", C.c_double), ("pf_alpha", C.c_double), ("pf_beta", C.c_double), ("pf_omega", C.c_double),
         ("pf_eps", C.c_double),
         ("n_up", C.c_int32), ("n_upod", C.c_int32), ("n_grp", C.c_int32), ("n_ent", C.c_int32), ("n_pair", C.c_int32),
-        ("node_up_ptr", _I32P), ("up_od_ptr", _I32P), ("upod_od", _I32P), ("node_grp_ptr", _I32P),
-        ("grp_ent_ptr", _I32P), ("grp_allphys", _I32P), ("ent_link", _I32P), ("ent_dist", _F64P),
+        ("node_up_ptr", _I32P), ("up_slot", _I32P), ("up_od_ptr", _I32P), ("upod_od", _I32P), ("node_grp_ptr", _I32P),
+        ("grp_ent_ptr", _I32P), ("grp_allphys", _I32P), ("grp_node", _I32P), ("ent_link", _I32P), ("ent_dist", _F64P),
         ("turn_pair_ptr", _I32P), ("pair_ent", _I32P), ("pair_upod", _I32P),
     ]
 
@@ -97,6 +97,8 @@ def _load():
         "pedn_timer_begin": (C.c_int, [P]),
         "pedn_timer_end": (C.c_int, [P, C.POINTER(C.c_float)]),
         "pedn_reset": (C.c_int, [P]),
+        "pedn_profile_step": (C.c_int, [P, C.c_int32, C.POINTER(C.c_float)]),
+        "pedn_device_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _F64P, _F64P, C.c_uint64, _F64P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -119,7 +121,7 @@ def lib():
 EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
-           "pedn_device_ptr", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset"]
+           "pedn_device_ptr", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step"]
 
 
 class ModelError(RuntimeError):
@@ -235,6 +237,12 @@ class Engine:
         if bits & 4:
             raise IndexError(msg)
         raise ModelError(msg, flags)
+
+    def profile_step(self, t):
+        """One step with per-kernel HIP-event timing: (turn_prob_ms, node_ms, link_ms)."""
+        ms = (C.c_float * 3)()
+        self._ck(self._lib.pedn_profile_step(self._h, int(t), ms))
+        return tuple(float(x) for x in ms)
 
     def timer_begin(self):
         self._ck(self._lib.pedn_timer_begin(self._h))

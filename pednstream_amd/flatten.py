@@ -105,7 +105,7 @@ def flatten_network(net) -> dict:
 
     node_dyn = np.zeros(N, dtype=I32)
     node_up_ptr, up_slot, up_od_ptr, upod_od = [0], [], [0], []
-    node_grp_ptr, grp_ent_ptr, grp_allphys, grp_up, ent_link, ent_dist = [0], [0], [], [], [], []
+    node_grp_ptr, grp_ent_ptr, grp_allphys, grp_up, grp_node, ent_link, ent_dist = [0], [0], [], [], [], [], []
     pair_ptr = [0]
     pair_ent, pair_upod = [], []
     for nd in nodes:
@@ -140,6 +140,7 @@ def flatten_network(net) -> dict:
                     grp_ent_ptr.append(len(ent_link))
                     grp_allphys.append(allphys)
                     grp_up.append(up_ids.index(up))
+                    grp_node.append(nd.index)
             for i, up in enumerate(up_ids):
                 for j, dn in enumerate(dn_ids):
                     if up == dn:
@@ -162,6 +163,7 @@ def flatten_network(net) -> dict:
     m["grp_ent_ptr"] = np.array(grp_ent_ptr, dtype=I32)
     m["grp_allphys"] = np.array(grp_allphys, dtype=I32)
     m["grp_up"] = np.array(grp_up, dtype=I32)
+    m["grp_node"] = np.array(grp_node, dtype=I32)
     m["ent_link"] = np.array(ent_link, dtype=I32)
     m["ent_dist"] = np.array(ent_dist, dtype=F64)
     m["turn_pair_ptr"] = np.array(pair_ptr, dtype=I32)

@@ -34,6 +34,7 @@ def lib():
         L.pedn_oracle_create.argtypes = [C.POINTER(ModelDesc), C.c_uint64, C.c_int32, C.c_int32]
         L.pedn_oracle_destroy.argtypes = [P]
         L.pedn_oracle_reset.argtypes = [P]
+        L.pedn_oracle_reseed.argtypes = [P, C.c_uint64, C.c_int32]
         L.pedn_oracle_step.argtypes = [P, C.c_int]
         L.pedn_oracle_run.argtypes = [P, C.c_int, C.c_int]
         L.pedn_oracle_run_many.argtypes = [C.POINTER(P), C.c_int, C.c_int, C.c_int]
@@ -89,6 +90,11 @@ class Oracle:
 
     def run(self, t0, t1):
         return self.L.pedn_oracle_run(self.h, int(t0), int(t1))
+
+    def reset(self, seed=None, replica=None):
+        self.L.pedn_oracle_reset(self.h)
+        if seed is not None:
+            self.L.pedn_oracle_reseed(self.h, int(seed), int(replica or 0))
 
     def flags(self):
         return int(self.L.pedn_oracle_flags(self.h))

@@ -1,0 +1,227 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu).  Everything goes through the C-ABI of
+pednstream_amd/csrc/libpedn_hip.so; the CPU oracle and the reference goldens are the checkers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_driver as od
+from golden_util import ALL_FIELDS, F64_FIELDS, Golden, apply_mutation, build_network, compare_fields
+from pednstream_amd import engine as eng
+from pednstream_amd.flatten import flatten_network
+from pednstream_amd.network import LINK_FIELDS
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full", "i45_prefix", "delft_prefix",
+         "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky"]
+
+
+def _dev_math(op, a, b=None, seed=0):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty_like(a)
+    P = C.POINTER(C.c_double)
+    bp = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    rc = eng.lib().pedn_device_math(0, op, len(a), a.ctypes.data_as(P), None if bp is None else bp.ctypes.data_as(P),
+                                    seed, out.ctypes.data_as(P))
+    assert rc == 0, eng.lib().pedn_last_error(None)
+    return out
+
+
+def test_device_arithmetic_matches_oracle_bit_for_bit():
+    L = od.lib()
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.random(50000).astype(np.float32).astype(np.float64), [0.0, 1.0, 0.5, 2.0 ** -24, 1e-30]])
+    for y in (0.8, 2.0, 3.0):
+        yy = np.full_like(x, np.float32(y))
+        got = _dev_math(0, x, yy)
+        want = np.array([L.pedn_oracle_powf(float(v), float(np.float32(y))) for v in x], dtype=np.float64)
+        assert np.array_equal(got, want), f"powf y={y}"
+    xs = np.concatenate([np.linspace(-60, 5, 60001), -rng.random(20000) * 30])
+    assert np.array_equal(_dev_math(1, xs), np.array([L.pedn_oracle_exp(float(v)) for v in xs]))
+    pos = rng.random(50000) * 1e4
+    assert np.array_equal(_dev_math(2, pos), np.sqrt(pos))
+    den = rng.random(50000) + 1e-3
+    assert np.array_equal(_dev_math(3, pos, den), pos / den)
+    f32 = (pos.astype(np.float32) / den.astype(np.float32)).astype(np.float64)
+    assert np.array_equal(_dev_math(4, pos.astype(np.float32).astype(np.float64), den.astype(np.float32).astype(np.float64)), f32)
+    n = rng.choice([0, 1, 3, 16, 17, 100, 5000, 40000], size=4000).astype(np.float64)
+    p = rng.random(4000).astype(np.float32).astype(np.float64)
+    got = _dev_math(5, n, p, seed=12345678901)
+    want = np.array([L.pedn_oracle_binomial(int(a), float(b), 12345678901, i, 7, 11, 0) for i, (a, b) in enumerate(zip(n, p))], dtype=np.float64)
+    assert np.array_equal(got, want)
+    sig = np.full(4000, 0.05)
+    got = _dev_math(6, sig, seed=77)
+    want = np.array([L.pedn_oracle_normal(0.05, 77, i, 7, 11) for i in range(4000)])
+    assert np.array_equal(got, want)
+
+
+def _run_engine_on_golden(g, n_replicas=1):
+    net = build_network(g, n_replicas=n_replicas, replica_offset=g.replica, rng_seed=g.seed, rng_mode=g.mode)
+    last = g.steps
+    tfh = []
+    for t in range(1, last):
+        net.network_loading(t)
+        tfh.append(np.concatenate([net._engine.get_turning_fractions(nd.index, 0) for nd in net.nodes.values()]))
+        for mut in g.mutations:
+            if mut[0] == t:
+                apply_mutation(net, mut)
+    return net, np.array(tfh)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_engine_reproduces_reference_goldens(case):
+    """HIP path vs the reference itself (goldens captured under the injected RNG): bit-exact on all 13 arrays."""
+    g = Golden(case)
+    net, tfh = _run_engine_on_golden(g)
+    e = net._engine
+    rc, flags = e.error_flags()
+    assert rc == 0
+    L = e.n_links
+
+    def field(name):
+        fid = LINK_FIELDS[name][0]
+        return e.read_block(fid, 0, g.steps)[:, :, 0].T      # [columns, t]
+
+    problems = compare_fields(field, g, L, g.steps)
+    assert not problems, "\n".join(problems)
+    if e.n_all > L:
+        for tag, off in (("vin", 0), ("vout", 1)):
+            for name in ("inflow", "outflow", "cumulative_inflow", "cumulative_outflow"):
+                mine = field(name)[L + off::2, :g.steps]
+                assert np.array_equal(mine, g.state(f"{tag}_{name}")[:, :g.steps]), (tag, name)
+    assert np.max(np.abs(tfh - g.z["tf_hist"]), initial=0.0) <= 4.5e-16
+    # link views (reference attribute surface) read the same numbers
+    key = tuple(g.static("link_uv")[0])
+    lk = net.links[key]
+    assert np.array_equal(np.asarray(lk.cumulative_inflow)[:g.steps], g.state("cumulative_inflow")[0, :g.steps])
+    assert lk.density[g.steps - 1] == g.state("density")[0, g.steps - 1]
+    net.close()
+
+
+def replica_demand(T, r, base=20.0, peak=25.0):
+    t = np.arange(T)
+    lam = base + peak * np.exp(-(t - T / 4) ** 2 / (2 * (T / 20) ** 2)) + peak * np.exp(-(t - 3 * T / 4) ** 2 / (2 * (T / 20) ** 2))
+    return np.random.default_rng(1000 + r).poisson(lam).astype(np.float64)
+
+
+def test_config2_nine_intersections_256_replicas_vs_oracle_and_goldens():
+    """BASELINE config #2: nine_intersections x 256 replicas, per-replica demand and RNG key; replicas 0..3 against the
+    reference goldens, replicas 0..7 and 255 against the CPU oracle, all bit-exact (f32 fields included)."""
+    R, steps = 256, 160
+    g0 = Golden("nine_replica0")
+    net = build_network(g0, n_replicas=R, rng_seed=0)
+    e = net.engine()
+    origins = {0: 0, 8: 1, 2: 2}
+    for r in range(R):
+        for nid, k in origins.items():
+            e.set_demand(net.nodes[nid].index, replica_demand(500, 3 * r + k, peak=50.0 if nid == 2 else 25.0), replica=r)
+    net._dirty_demand = set()
+    net.run(1, steps)
+    blocks = {name: e.read_block(LINK_FIELDS[name][0], 0, steps) for name in ALL_FIELDS}    # [t, L, R]
+    for r in range(4):
+        g = Golden(f"nine_replica{r}")
+        problems = compare_fields(lambda name: blocks[name][:, :, r].T, g, e.n_links, steps)
+        assert not problems, f"replica {r}:\n" + "\n".join(problems)
+    model = flatten_network(net)
+    for r in (0, 1, 2, 3, 4, 5, 6, 7, 255):
+        o = od.Oracle(model, seed=0, replica=r)
+        for nid, k in origins.items():
+            o.set_demand(net.nodes[nid].index, replica_demand(500, 3 * r + k, peak=50.0 if nid == 2 else 25.0))
+        o.run(1, steps)
+        for name in ALL_FIELDS:
+            mine = blocks[name][:, :e.n_links, r].T
+            assert np.array_equal(mine, o.field(name)[:e.n_links, :steps]), (r, name)
+    net.close()
+
+
+@pytest.mark.parametrize("name,replicas,steps", [("delft", 64, 60), ("melbourne", 128, 120), ("45_intersections", 64, 200)])
+def test_engine_equals_oracle_on_large_networks(name, replicas, steps):
+    """Same seeded inputs through the HIP path and the CPU oracle; sampled replicas, all fields bit-exact."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    np.random.seed(99)
+    net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=replicas, rng_seed=5, replica_offset=1000)
+    net.run(1, steps)
+    e = net._engine
+    model = flatten_network(net)
+    for r in (0, replicas // 2, replicas - 1):
+        o = od.Oracle(model, seed=5, replica=1000 + r)
+        o.run(1, steps)
+        assert o.flags() == 0
+        for fname in ALL_FIELDS:
+            fid = LINK_FIELDS[fname][0]
+            mine = e.read_block(fid, 0, steps, rep0=r, rep1=r + 1)[:, :, 0].T
+            assert np.array_equal(mine[:e.n_links], o.field(fname)[:e.n_links, :steps]), (r, fname)
+    net.close()
+
+
+def test_full_size_melbourne_1024_invariants():
+    """BASELINE config at full size (melbourne x 1024): size-independent properties of the model
+    (SURVEY section 4): cumulative = running sum of flows, pedestrian conservation, non-negativity,
+    outflow <= sending flow, inflow <= receiving flow, node flow conservation, replica independence."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    R, steps = 1024, 140
+    net = NetworkEnvGenerator(DATA).create_network("melbourne", verbose=False, n_replicas=R, rng_seed=1)
+    e = net.engine()
+    # replicas 1000.. share demand with replica 0 but not its RNG key; make two replicas exact twins via the key offset
+    net.run(1, steps)
+    rc, _ = e.error_flags()
+    assert rc == 0
+    L = e.n_links
+    rs = slice(0, 64)
+    inflow = e.read_block(0, 0, steps, rep0=0, rep1=64)
+    outflow = e.read_block(1, 0, steps, rep0=0, rep1=64)
+    ci = e.read_block(2, 0, steps, rep0=0, rep1=64)
+    co = e.read_block(3, 0, steps, rep0=0, rep1=64)
+    S = e.read_block(4, 0, steps, rep0=0, rep1=64)
+    Rv = e.read_block(5, 0, steps, rep0=0, rep1=64)
+    N = e.read_block(9, 0, steps, rep0=0, rep1=64)
+    assert np.array_equal(ci, np.cumsum(inflow, axis=0)) and np.array_equal(co, np.cumsum(outflow, axis=0))
+    assert (inflow >= 0).all() and (outflow >= 0).all()
+    assert np.array_equal(N.astype(np.float64), (ci - co)[:, :L])          # integer-valued counts: exact in f32
+    assert (outflow[1:, :L] <= S[:-1] + 1e-9).all()
+    assert (inflow[1:, :L] <= Rv[:-1] + 1e-9).all()
+    m = flatten_network(net)
+    for n in range(m["n_nodes"]):
+        a, b = m["node_slot_ptr"][n], m["node_slot_ptr"][n + 1]
+        q_out = outflow[:, m["slot_in_link"][a:b]].sum(axis=1)
+        q_in = inflow[:, m["slot_out_link"][a:b]].sum(axis=1)
+        assert np.array_equal(q_out, q_in), f"node {n}"
+    assert ci[-1].sum() > 0                                                   # pedestrians actually entered
+    # replicas differ (different RNG keys) ...
+    d = e.read_block(10, steps - 1, steps)[0]
+    assert not np.array_equal(d[:, 0], d[:, 1])
+    # ... and one replica re-run alone with the same key reproduces itself exactly
+    solo = NetworkEnvGenerator(DATA).create_network("melbourne", verbose=False, n_replicas=1, rng_seed=1, replica_offset=777)
+    solo.run(1, steps)
+    d_solo = solo._engine.read_block(10, steps - 1, steps)[0][:, 0]
+    assert np.array_equal(d_solo, d[:, 777])
+    solo.close()
+    net.close()
+
+
+def test_c_abi_argument_errors_and_reset():
+    g = Golden("six_node_full")
+    net = build_network(g, n_replicas=3)
+    e = net.engine()
+    lib = eng.lib()
+    assert lib.pedn_step(e._h, 0) < 0 and b"outside" in lib.pedn_last_error(e._h)
+    assert lib.pedn_set_width(e._h, 1, 10 ** 6, -1, 1.0) < 0
+    assert lib.pedn_set_demand(e._h, net.nodes[0].index, -1, np.zeros(4).ctypes.data_as(C.POINTER(C.c_double)), 4) < 0  # node 0 has no virtual link
+    with pytest.raises(IndexError):
+        net.network_loading(10 ** 6)
+    net.run(1, 50)
+    a = e.read_block(2, 0, 50)
+    e.reset()
+    assert (e.read_block(2, 0, 50) == 0).all() and (e.read_block(4, 0, 50) == -1).all()
+    net.run(1, 50)
+    assert np.array_equal(a, e.read_block(2, 0, 50))
+    # negative demand trips the reference's "negative flows" check (node.py:218-219) -> sticky flag -> exception
+    net.nodes[1].demand[60] = -5.0
+    with pytest.raises(eng.ModelError):
+        net.run(50, 70)
+    net.close()
