@@ -68,6 +68,22 @@ def cpu_baseline(model, net, origin_nodes, threads, seconds_target=12.0):
             "sample": f"{done} replicas x {T - 1} steps of melbourne on {threads} host threads (oracle/pedn_oracle.c, {el:.1f} s)"}
 
 
+def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc.json, written by
+    tools/summarize_profiles.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  bench.py cannot
+    collect PMC counters on itself; the number is only reported for the workload it was measured on."""
+    import glob
+    if network != "melbourne" or replicas != 1024:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    k = d.get("kernels", {}).get(kernel)
+    return (k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +179,7 @@ def main():
         value = total_lu / wall
         node_bytes = NODE_KERNEL_BYTES * L * R
         achieved = node_bytes / (node_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic("node_kernel", args.network, R)
         out = {
             "metric": "link-updates/sec (links x replicas x steps/sec)", "value": value, "unit": "link-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -172,7 +189,7 @@ def main():
                        "replicas_per_gpu": R, "links": L, "parallelism": f"replica-sharded x{world}, no step-path collective"},
             "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "hbm", "kernel": "node_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": node_bytes, "avg_launch_ms": float(node_ms),
                          "other_kernels_ms": {"link_kernel": float(link_ms), "turn_prob_kernel": float(tf_ms)},
                          "whole_step_GBps": BYTES_PER_LINK_UPDATE * L * R / ((node_ms + link_ms + tf_ms) * 1e-3) / 1e9},

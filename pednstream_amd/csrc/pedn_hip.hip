@@ -18,6 +18,7 @@
 // Compile with -ffp-contract=off: results must match the reference bit for bit (cumulative counts) and the
 // arithmetic below spells out every binary32 / binary64 rounding point of numpy's scalar semantics.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -513,6 +514,7 @@ __global__ void device_math_kernel(int op, int n, const double* a, const double*
     case 4: out[i] = (double)((float)x / (float)y); break;
     case 5: out[i] = rng_binomial((long long)x, y, key, 0); break;
     case 6: key.site = 3u; out[i] = x * rng_z(key); break;
+    case 7: out[i] = x + y; break;  // streaming calibration: 16 B read + 8 B written per lane, 8-byte accesses
     default: out[i] = 0.0;
   }
 }
@@ -924,27 +926,27 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
   DevView& v = s->v;
-  hipEvent_t ev[4];
-  for (int i = 0; i < 4; ++i) HIP_TRY(s, hipEventCreate(&ev[i]));
+  // hipExtLaunchKernelGGL start/stop events carry the dispatch's own begin/end timestamps (what rocprofv3 reports),
+  // not the enqueue-to-completion interval an ordinary hipEventRecord bracket would measure.
+  hipEvent_t ev[6];
+  for (int i = 0; i < 6; ++i) HIP_TRY(s, hipEventCreate(&ev[i]));
   const unsigned rgroups = (unsigned)(v.RS / 64);
-  HIP_TRY(s, hipEventRecord(ev[0], s->stream));
   if (v.n_grp > 0) {
     size_t n = (size_t)v.n_grp * v.RS;
-    hipLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+    hipExtLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
   }
-  HIP_TRY(s, hipEventRecord(ev[1], s->stream));
-  hipLaunchKernelGGL(node_kernel, dim3((unsigned)s->n_blocks, rgroups), dim3(512), 0, s->stream, v, t);
-  HIP_TRY(s, hipEventRecord(ev[2], s->stream));
+  hipExtLaunchKernelGGL(node_kernel, dim3((unsigned)s->n_blocks, rgroups), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
   if (v.n_pairs_corr > 0) {
     size_t n = (size_t)v.n_pairs_corr * v.RS;
-    hipLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+    hipExtLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[4], ev[5], 0, v, t);
   }
-  HIP_TRY(s, hipEventRecord(ev[3], s->stream));
-  HIP_TRY(s, hipEventSynchronize(ev[3]));
   HIP_TRY(s, hipGetLastError());
-  for (int i = 0; i < 3; ++i) HIP_TRY(s, hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
-  if (v.n_grp == 0) ms[0] = 0.0f;
-  for (int i = 0; i < 4; ++i) hipEventDestroy(ev[i]);
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  ms[0] = ms[1] = ms[2] = 0.0f;
+  if (v.n_grp > 0) HIP_TRY(s, hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+  HIP_TRY(s, hipEventElapsedTime(&ms[1], ev[2], ev[3]));
+  if (v.n_pairs_corr > 0) HIP_TRY(s, hipEventElapsedTime(&ms[2], ev[4], ev[5]));
+  for (int i = 0; i < 6; ++i) hipEventDestroy(ev[i]);
   return PEDN_OK;
 }
 
