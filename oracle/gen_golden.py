@@ -87,6 +87,8 @@ def direct_case(case, adj, params, origin_nodes, destination_nodes=(), steps=Non
         for (mt, kind, u, v, val) in muts:
             if mt == t and kind == "back_gate_set":
                 n.links[(u, v)].back_gate_width = val
+            elif mt == t and kind == "separator_set":
+                n.links[(u, v)].separator_width = val
 
     net, static, state, extras = rh.run_reference(None, steps=steps, seed=seed, replica=replica, mutate=mutate,
                                                   record_tf=True, network=net)
@@ -144,6 +146,32 @@ FORKY_PARAMS = {
 }
 
 
+# Parameter sets no reference scenario uses (smulders FD, non-dyadic k_c / k_j / dt, bi_factor != 1, activity + noise
+# together, per-link overrides): they pin the precision ledger of the oracle away from the "nice" yaml values.
+ODD_ADJ = [[0, 1, 1, 0, 0, 0, 0], [1, 0, 1, 1, 0, 0, 0], [1, 1, 0, 1, 1, 0, 0], [0, 1, 1, 0, 1, 1, 0],
+           [0, 0, 1, 1, 0, 1, 1], [0, 0, 0, 1, 1, 0, 1], [0, 0, 0, 0, 1, 1, 0]]
+ODD_PARAMS = {
+    "unit_time": 5, "simulation_steps": 400, "assign_flows_type": "classic", "seed": 7,
+    "path_finder": {"k_paths": 3, "temp": 3.7, "alpha": 1.3, "beta": 0.7, "omega": 0.45, "std_dev": 0.05},
+    "default_link": {"length": 37.3, "width": 2.5, "free_flow_speed": 1.27, "k_critical": 1.73, "k_jam": 5.4, "gamma": 0.013,
+                     "speed_noise_std": 0.03, "fd_type": "smulders", "bi_factor": 1.5, "activity_probability": 0.15},
+    "links": {"1_3": {"length": 61.9, "fd_type": "greenshields", "k_critical": 2.1},
+              "2_4": {"length": 45.5, "width": 1.7, "fd_type": "yperman", "activity_probability": 0},
+              "3_5": {"length": 29.1, "speed_noise_std": 0, "gamma": 0},
+              "4_6": {"length": 88.8, "free_flow_speed": 0.93, "k_jam": 6.6}},
+    "controllers": {"enabled": True, "nodes": [3]},
+    "demand": {"origin_0": {"peak_lambda": 22, "base_lambda": 9}, "origin_6": {"pattern": "constant", "base_lambda": 7.5}},
+}
+SEP_ADJ = [[0, 1, 0, 0, 0], [1, 0, 1, 0, 0], [0, 1, 0, 1, 0], [0, 0, 1, 0, 1], [0, 0, 0, 1, 0]]
+SEP_PARAMS = {
+    "unit_time": 10, "simulation_steps": 300, "assign_flows_type": "classic", "seed": 3,
+    "default_link": {"length": 80, "width": 3.2, "free_flow_speed": 1.2, "k_critical": 1.9, "k_jam": 5.8, "gamma": 0.02,
+                     "speed_noise_std": 0.04, "fd_type": "yperman", "bi_factor": 1, "activity_probability": 0.05},
+    "links": {"1_2": {"controller_type": "separator"}, "2_3": {"controller_type": "separator", "length": 55.5, "fd_type": "greenshields"}},
+    "demand": {"origin_0": {"peak_lambda": 30, "base_lambda": 18}, "origin_4": {"peak_lambda": 28, "base_lambda": 16}},
+}
+
+
 def replica_demand(T, r, base=20.0, peak=25.0):
     """Config #2 per-replica origin demand: Poisson around the gaussian-peaks profile, numpy Generator(1000+r)."""
     t = np.arange(T)
@@ -167,6 +195,10 @@ CASES = {
     "forky": lambda: direct_case("forky", FORKY_ADJ, FORKY_PARAMS, [0, 4], tf_nodes=[1],
                                  tf_values=[[1, 0, 0.5, 0.5, 0, 1]],
                                  mutations=[(40, "back_gate_set", 1, 2, 0.0), (120, "back_gate_set", 1, 2, 1.0)]),
+    "odd_params": lambda: direct_case("odd_params", ODD_ADJ, ODD_PARAMS, [0, 6], destination_nodes=[6, 0], seed=11, replica=5),
+    "odd_separators": lambda: direct_case("odd_separators", SEP_ADJ, SEP_PARAMS, [0, 4], seed=2, replica=9,
+                                          mutations=[(60, "separator_set", 1, 2, 0.9), (140, "separator_set", 2, 3, 2.4),
+                                                     (200, "back_gate_set", 3, 4, 1.1)]),
 }
 for _r in range(4):
     CASES[f"nine_replica{_r}"] = (lambda r=_r: scenario_case(
