@@ -43,6 +43,13 @@ struct LinkP {  // static per-link parameters, wave-uniform on the device
   int32_t pad[2];
 };
 
+struct EntS {  // one downstream entry of a softmax group (update_node_turn_probs, path_finder.py:561-589)
+  int32_t link, rev, sep;  // outgoing link (-1: virtual), its reverse, separator flag
+  float area32;            // float32(length * width) of a plain link
+  double vf, kc;           // for the capacity fallback back_gate * v_f * k_c * dt (:576)
+  double dist_term;        // alpha * distance / (sum of the group's distances + 1e-6), static (:582)
+};
+
 struct DevView {
   double* f64[7];
   float* f32[6];
@@ -52,11 +59,14 @@ struct DevView {
   uint32_t* flags;
   const LinkP* lp;
   const int4* wave_desc;
-  const int32_t *node_kind, *node_slot_ptr, *node_turn_ptr, *node_demand_row, *node_dyn, *slot_in, *slot_out, *slot_up;
-  const int32_t *up_od_ptr, *upod_od, *grp_ent_ptr, *grp_allphys, *ent_link, *turn_pair_ptr, *pair_ent, *pair_upod;
+  const int32_t *node_kind, *node_slot_ptr, *node_turn_ptr, *node_demand_row, *node_dyn, *slot_in, *slot_out;
+  const int32_t *grp_ent_ptr, *grp_allphys, *ent_pair, *turn_pair_ptr;
+  const struct EntS* ents;      // static per-entry data of the softmax groups
+  const int32_t* grp_multi;     // groups with more than one downstream entry (single-entry groups have P = 1 exactly)
+  const int32_t* pair_const;    // [n_pair] 1: the product's probability is the constant 1
+  const double* pair_pod;  // [T+1][n_pair] P(od | up) of the pair's upstream group, replica independent
   const int32_t* pair_a;  // corridor list for link_kernel
-  const double* ent_dist;
-  int32_t L, Lall, T1, RS, R, W, n_grp, n_pairs_corr;
+  int32_t L, Lall, T1, RS, R, W, n_grp, n_multi, n_pairs_corr, n_pair;
   double dt, pf_temp, pf_alpha, pf_beta, pf_omega, pf_eps;
   uint32_t k0, k1, replica_offset;
   int32_t meanfield;
@@ -178,36 +188,36 @@ __device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int
 }
 
 // ------------------------------------------------------------------------------------------------- kernels
-// P(down | up, od) for every softmax group (update_node_turn_probs, path_finder.py:561-589)
-__global__ __launch_bounds__(256) void turn_prob_kernel(DevView v, int t) {
+// P(down | up, od) for every softmax group with more than one downstream (update_node_turn_probs, path_finder.py:561-589).
+// A group with a single downstream has P = e/e = 1 exactly; those are constants and never recomputed.
+__global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
   const int RS = v.RS;
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int g = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
+  int gi = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
   int r = (int)(gid % (size_t)RS);
-  if (g >= v.n_grp) return;
+  if (gi >= v.n_multi) return;
+  const int g = v.grp_multi[gi];
   uint32_t fl = 0;
   const int a = v.grp_ent_ptr[g], n = v.grp_ent_ptr[g + 1] - a;
   const int allphys = v.grp_allphys[g];
+  const int t2 = wrap_idx(t - 2, v.T1, fl);
   double cap[PEDN_MAX_DEGREE - 1];
   float kf[PEDN_MAX_DEGREE - 1];
-  double sumd = 0.0, sumc = 0.0;
+  double sumc = 0.0;
 #pragma unroll
   for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
     if (e < n) {
-      int l = v.ent_link[a + e];
-      if (l >= 0) {
-        const LinkP P = v.lp[l];
-        // density uses the live width for a separator
-        if (P.sep) kf[e] = v.f32[G_K][at(t - 1, l, v.L, RS, r)];
-        else kf[e] = dens_at(v, P, l, t - 1, r);
-        double c = v.f64[F_R][at(wrap_idx(t - 2, v.T1, fl), l, v.L, RS, r)];
-        cap[e] = c >= 0.0 ? c : v.back[(size_t)l * RS + r] * P.vf * P.kc * v.dt;  // :575-576
+      const EntS E = v.ents[a + e];
+      if (E.link >= 0) {
+        if (E.sep) kf[e] = v.f32[G_K][at(t - 1, E.link, v.L, RS, r)];  // Separator.get_density, link.py:427-428
+        else kf[e] = (v.f32[G_N][at(t - 1, E.link, v.L, RS, r)] + v.f32[G_N][at(t - 1, E.rev, v.L, RS, r)]) / E.area32;
+        double c = v.f64[F_R][at(t2, E.link, v.L, RS, r)];
+        if (!(c >= 0.0)) c = v.back[(size_t)E.link * RS + r] * E.vf * E.kc * v.dt;  // :575-576
+        cap[e] = c;
       } else {
         kf[e] = 0.0f;
         cap[e] = 100.0;  // :577-579
       }
-      double d = v.ent_dist[a + e];
-      sumd = (e == 0) ? d : sumd + d;
       sumc = (e == 0) ? cap[e] : sumc + cap[e];
     }
   }
@@ -226,19 +236,23 @@ __global__ __launch_bounds__(256) void turn_prob_kernel(DevView v, int t) {
         if (!(x > 0.0)) x = 0.0;
         nd = v.pf_beta * (x / 8.0);
       }
-      double u = (v.pf_alpha * v.ent_dist[a + e]) / (sumd + 1e-6) + nd - (v.pf_omega * cap[e]) / (sumc + 1e-6) + v.pf_eps;
+      double u = v.ents[a + e].dist_term + nd - (v.pf_omega * cap[e]) / (sumc + 1e-6) + v.pf_eps;
       ex[e] = pedn_exp(-v.pf_temp * u);
       esum = (e == 0) ? ex[e] : esum + ex[e];
     }
   }
 #pragma unroll
-  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e)
-    if (e < n) v.ent_p[(size_t)(a + e) * RS + r] = ex[e] / esum;
+  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
+    if (e < n) {
+      const int q = v.ent_pair[a + e];  // slot of the (turn, od) product that consumes this probability
+      if (q >= 0) v.ent_p[(size_t)q * RS + r] = ex[e] / esum;
+    }
+  }
   if (fl) atomicOr(&v.flags[r], fl);
 }
 
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
-__global__ __launch_bounds__(512) void node_kernel(DevView v, int t) {
+__global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
   __shared__ double sPS[64 * 64];  // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
   __shared__ double sR[8 * 64];    // receiving flow of each wave's outgoing link
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -281,23 +295,26 @@ __global__ __launch_bounds__(512) void node_kernel(DevView v, int t) {
       const int turn0 = v.node_turn_ptr[node] + slot * (m - 1);
       double tfr[PEDN_MAX_DEGREE - 1];
       if (v.node_dyn[node]) {
-        const int u = v.slot_up[s0 + slot];
-        double tot = 0.0;
-        int nu = 0;
-        if (u >= 0) {
-          const int qa = v.up_od_ptr[u], qb = v.up_od_ptr[u + 1];
-          nu = qb - qa;
-          for (int q = qa; q < qb; ++q) tot += v.od_w[(size_t)v.upod_od[q] * v.T1 + t];  // :599-605
-        }
+        // tf[turn] = sum over the turn's (od) products P(down | up, od) * P(od | up)   (path_finder.py:668-686).
+        // The products of one row are contiguous: probabilities were stored in pair order by turn_prob_kernel and
+        // P(od | up) (replica independent, :599-615) was tabulated per pair and step on the host.
+        const double* pod = v.pair_pod + (size_t)t * v.n_pair;
         double rowsum = 0.0;
 #pragma unroll
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
           if (jj < m - 1) {
             double acc = 0.0;
-            for (int q = v.turn_pair_ptr[turn0 + jj]; q < v.turn_pair_ptr[turn0 + jj + 1]; ++q) {
-              double w = v.od_w[(size_t)v.upod_od[v.pair_upod[q]] * v.T1 + t];
-              double pod = tot > 0.0 ? w / tot : (nu > 0 ? 1.0 / (double)nu : 0.0);  // :608-615
-              acc += v.ent_p[(size_t)v.pair_ent[q] * RS + r] * pod;                    // :680-685
+            const int q1 = v.turn_pair_ptr[turn0 + jj + 1];
+            for (int q = v.turn_pair_ptr[turn0 + jj]; q < q1; q += 4) {
+              // loads first (independent), then the strictly sequential sum the reference performs
+              double e0 = v.pair_const[q] ? 1.0 : v.ent_p[(size_t)q * RS + r];
+              double e1 = q + 1 < q1 ? (v.pair_const[q + 1] ? 1.0 : v.ent_p[(size_t)(q + 1) * RS + r]) : 0.0;
+              double e2 = q + 2 < q1 ? (v.pair_const[q + 2] ? 1.0 : v.ent_p[(size_t)(q + 2) * RS + r]) : 0.0;
+              double e3 = q + 3 < q1 ? (v.pair_const[q + 3] ? 1.0 : v.ent_p[(size_t)(q + 3) * RS + r]) : 0.0;
+              acc += e0 * pod[q];
+              if (q + 1 < q1) acc += e1 * pod[q + 1];
+              if (q + 2 < q1) acc += e2 * pod[q + 2];
+              if (q + 3 < q1) acc += e3 * pod[q + 3];
             }
             tfr[jj] = acc;
             rowsum = (jj == 0) ? acc : rowsum + acc;
@@ -430,7 +447,7 @@ __device__ __forceinline__ void speed_update(const DevView& v, const LinkP& P, i
 }
 
 // Network.update_link_states (network.py:257-264): both directions of one corridor per lane
-__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) {
+__global__ __launch_bounds__(256, 8) void link_kernel(DevView v, int t) {
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
@@ -529,6 +546,10 @@ struct pedn_sim {
   int device = 0;
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
   std::vector<int32_t> node_turn_ptr, node_demand_row;
+  std::vector<int32_t> h_up_od_ptr, h_upod_od, h_pair_upod;  // route-choice tables needed to re-tabulate P(od | up)
+  std::vector<double> h_od_w;
+  double* d_pair_pod = nullptr;
+  int n_pair = 0, n_up = 0;
   std::vector<void*> allocs;
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -590,6 +611,28 @@ static int reset_state(pedn_sim* s) {
     hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s->stream, v);
     HIP_TRY(s, hipGetLastError());
   }
+  return PEDN_OK;
+}
+
+// P(od | up)[t] = w_od[t] / sum over the upstream's ODs (uniform when the sum is 0), path_finder.py:599-615; the sum runs in
+// table order.  Replica independent, so it is tabulated once per (step, product) on the host with the same binary64 operations.
+static int tabulate_pair_pod(pedn_sim* s) {
+  const int T1 = s->v.T1, np = s->n_pair;
+  if (np == 0) return PEDN_OK;
+  std::vector<double> upod((size_t)s->h_upod_od.size());
+  std::vector<double> table((size_t)T1 * np);
+  for (int t = 0; t < T1; ++t) {
+    for (int u = 0; u < s->n_up; ++u) {
+      const int a = s->h_up_od_ptr[u], b = s->h_up_od_ptr[u + 1];
+      double tot = 0.0;
+      for (int q = a; q < b; ++q) tot += s->h_od_w[(size_t)s->h_upod_od[q] * T1 + t];
+      for (int q = a; q < b; ++q)
+        upod[q] = tot > 0.0 ? s->h_od_w[(size_t)s->h_upod_od[q] * T1 + t] / tot : (b - a > 0 ? 1.0 / (double)(b - a) : 0.0);
+    }
+    for (int q = 0; q < np; ++q) table[(size_t)t * np + q] = upod[s->h_pair_upod[q]];
+  }
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipMemcpy(s->d_pair_pod, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice));
   return PEDN_OK;
 }
 
@@ -688,21 +731,53 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   TRY(upload(s, m->node_dyn, N, &v.node_dyn));
   TRY(upload(s, m->slot_in_link, n_slots, &v.slot_in));
   TRY(upload(s, m->slot_out_link, n_slots, &v.slot_out));
-  {
-    std::vector<int32_t> slot_up(n_slots, -1);
-    for (int n = 0; n < N; ++n)
-      for (int u = m->node_up_ptr[n]; u < m->node_up_ptr[n + 1]; ++u) slot_up[m->node_slot_ptr[n] + m->up_slot[u]] = u;
-    TRY(upload(s, slot_up.data(), slot_up.size(), &v.slot_up));
+  s->h_up_od_ptr.assign(m->up_od_ptr, m->up_od_ptr + m->n_up + 1);
+  s->h_upod_od.assign(m->upod_od, m->upod_od + m->n_upod);
+  s->h_pair_upod.assign(m->pair_upod, m->pair_upod + m->n_pair);
+  s->h_od_w.assign(m->od_w, m->od_w + (size_t)m->n_od * v.T1);
+  s->n_pair = m->n_pair;
+  s->n_up = m->n_up;
+  v.n_pair = m->n_pair;
+  {  // every softmax entry feeds exactly one (turn, od) product: store probabilities in product order
+    std::vector<int32_t> ent_pair(std::max(m->n_ent, 1), -1);
+    for (int q = 0; q < m->n_pair; ++q) {
+      int e = m->pair_ent[q];
+      if (e < 0 || e >= m->n_ent || ent_pair[e] != -1) { pedn_destroy(s); return fail(nullptr, PEDN_E_ARG, "pair_ent is not injective"); }
+      ent_pair[e] = q;
+    }
+    TRY(upload(s, ent_pair.data(), ent_pair.size(), &v.ent_pair));
+    // exp(x)/exp(x) == 1 exactly as long as exp(x) is finite and non-zero; |x| <= temp * (|alpha| + |beta|*k_max/8 + |omega| + |eps|)
+    const double xmax = fabs(m->pf_temp) * (fabs(m->pf_alpha) + fabs(m->pf_beta) * 16.0 + fabs(m->pf_omega) + fabs(m->pf_eps));
+    const bool shortcut = xmax < 600.0;
+    std::vector<EntS> ents(std::max(m->n_ent, 1));
+    std::vector<int32_t> multi, pconst(std::max(m->n_pair, 1), 0);
+    for (int g = 0; g < m->n_grp; ++g) {
+      const int a = m->grp_ent_ptr[g], b = m->grp_ent_ptr[g + 1];
+      double sumd = 0.0;
+      for (int e = a; e < b; ++e) sumd = (e == a) ? m->ent_dist[e] : sumd + m->ent_dist[e];
+      for (int e = a; e < b; ++e) {
+        EntS& E = ents[e];
+        E.link = m->ent_link[e];
+        E.rev = E.sep = 0; E.area32 = 1.0f; E.vf = E.kc = 0.0;
+        if (E.link >= 0) {
+          if (E.link >= L) { pedn_destroy(s); return fail(nullptr, PEDN_E_ARG, "ent_link out of range"); }
+          E.rev = m->link_rev[E.link]; E.sep = m->link_sep[E.link];
+          E.area32 = (float)(m->link_length[E.link] * m->link_width[E.link]);
+          E.vf = m->link_vf[E.link]; E.kc = m->link_kc[E.link];
+        }
+        E.dist_term = (m->pf_alpha * m->ent_dist[e]) / (sumd + 1e-6);
+      }
+      if (b - a == 1 && shortcut) { if (ent_pair[a] >= 0) pconst[ent_pair[a]] = 1; }
+      else if (b - a >= 1) multi.push_back(g);
+    }
+    v.n_multi = (int)multi.size();
+    TRY(upload(s, ents.data(), ents.size(), &v.ents));
+    TRY(upload(s, multi.data(), multi.size(), &v.grp_multi));
+    TRY(upload(s, pconst.data(), pconst.size(), &v.pair_const));
   }
-  TRY(upload(s, m->up_od_ptr, m->n_up + 1, &v.up_od_ptr));
-  TRY(upload(s, m->upod_od, m->n_upod, &v.upod_od));
   TRY(upload(s, m->grp_ent_ptr, m->n_grp + 1, &v.grp_ent_ptr));
   TRY(upload(s, m->grp_allphys, m->n_grp, &v.grp_allphys));
-  TRY(upload(s, m->ent_link, m->n_ent, &v.ent_link));
-  TRY(upload(s, m->ent_dist, m->n_ent, &v.ent_dist));
   TRY(upload(s, m->turn_pair_ptr, m->n_turns + 1, &v.turn_pair_ptr));
-  TRY(upload(s, m->pair_ent, m->n_pair, &v.pair_ent));
-  TRY(upload(s, m->pair_upod, m->n_pair, &v.pair_upod));
   TRY(upload(s, m->od_w, (size_t)m->n_od * v.T1, &v.od_w));
   {  // corridors: one lane of link_kernel updates both directions
     std::vector<int32_t> pa;
@@ -750,7 +825,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     TRY(dalloc(s, (size_t)L * RS, &v.sepw));
     TRY(dalloc(s, (size_t)m->n_turns * RS, &v.tf));
     TRY(dalloc(s, (size_t)m->n_demand * T1 * RS, &v.demand));
-    TRY(dalloc(s, (size_t)m->n_ent * RS, &v.ent_p));
+    TRY(dalloc(s, (size_t)std::max(m->n_pair, m->n_ent) * RS, &v.ent_p));
+    TRY(dalloc(s, (size_t)m->n_pair * T1, &s->d_pair_pod));
+    v.pair_pod = s->d_pair_pod;
     TRY(dalloc(s, RS, &v.flags));
   }
   // initial widths, turning fractions, demand (broadcast to every replica)
@@ -783,7 +860,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
                          (int)rows, (size_t)0, (size_t)1, v.RS, 0, v.RS, 0, 1);
       HIP_TRY(s, hipStreamSynchronize(s->stream));
     }
-    if (m->n_ent) HIP_TRY(s, hipMemsetAsync(v.ent_p, 0, (size_t)m->n_ent * v.RS * 8, s->stream));
+    if (m->n_ent) HIP_TRY(s, hipMemsetAsync(v.ent_p, 0, (size_t)std::max(m->n_pair, m->n_ent) * v.RS * 8, s->stream));
+    TRY(tabulate_pair_pod(s));
   }
   {
     int rc = reset_state(s);
@@ -848,7 +926,8 @@ int pedn_set_od_weights(pedn_sim* s, int32_t od, const double* values, int32_t n
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemcpy((void*)(s->v.od_w + (size_t)od * s->v.T1), values, (size_t)n * 8, hipMemcpyHostToDevice));
-  return PEDN_OK;
+  std::copy(values, values + n, s->h_od_w.begin() + (size_t)od * s->v.T1);
+  return tabulate_pair_pod(s);
 }
 
 int pedn_set_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, const double* tf, int32_t n) {
@@ -900,8 +979,8 @@ int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
 static int launch_step(pedn_sim* s, int t) {
   DevView& v = s->v;
   const unsigned rgroups = (unsigned)(v.RS / 64);
-  if (v.n_grp > 0) {
-    size_t n = (size_t)v.n_grp * v.RS;
+  if (v.n_multi > 0) {
+    size_t n = (size_t)v.n_multi * v.RS;
     hipLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
   }
   hipLaunchKernelGGL(node_kernel, dim3((unsigned)s->n_blocks, rgroups), dim3(512), 0, s->stream, v, t);
@@ -931,8 +1010,8 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   hipEvent_t ev[6];
   for (int i = 0; i < 6; ++i) HIP_TRY(s, hipEventCreate(&ev[i]));
   const unsigned rgroups = (unsigned)(v.RS / 64);
-  if (v.n_grp > 0) {
-    size_t n = (size_t)v.n_grp * v.RS;
+  if (v.n_multi > 0) {
+    size_t n = (size_t)v.n_multi * v.RS;
     hipExtLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
   }
   hipExtLaunchKernelGGL(node_kernel, dim3((unsigned)s->n_blocks, rgroups), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
@@ -943,7 +1022,7 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   HIP_TRY(s, hipGetLastError());
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   ms[0] = ms[1] = ms[2] = 0.0f;
-  if (v.n_grp > 0) HIP_TRY(s, hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+  if (v.n_multi > 0) HIP_TRY(s, hipEventElapsedTime(&ms[0], ev[0], ev[1]));
   HIP_TRY(s, hipEventElapsedTime(&ms[1], ev[2], ev[3]));
   if (v.n_pairs_corr > 0) HIP_TRY(s, hipEventElapsedTime(&ms[2], ev[4], ev[5]));
   for (int i = 0; i < 6; ++i) hipEventDestroy(ev[i]);
