@@ -64,9 +64,11 @@ struct DevView {
   const struct EntS* ents;      // static per-entry data of the softmax groups
   const int32_t* grp_multi;     // groups with more than one downstream entry (single-entry groups have P = 1 exactly)
   const int32_t* pair_const;    // [n_pair] 1: the product's probability is the constant 1
+  const int32_t* turn_mode;     // [n_turns] 1: every product of the turn is constant -> fraction tabulated per step on the host
+  const double* turn_tab;       // [T+1][n_turns] tabulated raw fractions of such turns
   const double* pair_pod;  // [T+1][n_pair] P(od | up) of the pair's upstream group, replica independent
   const int32_t* pair_a;  // corridor list for link_kernel
-  int32_t L, Lall, T1, RS, R, W, n_grp, n_multi, n_pairs_corr, n_pair;
+  int32_t L, Lall, T1, RS, R, W, n_grp, n_multi, n_pairs_corr, n_pair, n_turns;
   double dt, pf_temp, pf_alpha, pf_beta, pf_omega, pf_eps;
   uint32_t k0, k1, replica_offset;
   int32_t meanfield;
@@ -304,7 +306,8 @@ __global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
           if (jj < m - 1) {
             double acc = 0.0;
-            const int q1 = v.turn_pair_ptr[turn0 + jj + 1];
+            const int q1 = v.turn_mode[turn0 + jj] ? 0 : v.turn_pair_ptr[turn0 + jj + 1];
+            if (v.turn_mode[turn0 + jj]) acc = v.turn_tab[(size_t)t * v.n_turns + turn0 + jj];
             for (int q = v.turn_pair_ptr[turn0 + jj]; q < q1; q += 4) {
               // loads first (independent), then the strictly sequential sum the reference performs
               double e0 = v.pair_const[q] ? 1.0 : v.ent_p[(size_t)q * RS + r];
@@ -548,7 +551,9 @@ struct pedn_sim {
   std::vector<int32_t> node_turn_ptr, node_demand_row;
   std::vector<int32_t> h_up_od_ptr, h_upod_od, h_pair_upod;  // route-choice tables needed to re-tabulate P(od | up)
   std::vector<double> h_od_w;
+  std::vector<int32_t> h_turn_pair_ptr, h_pair_const, h_turn_mode;
   double* d_pair_pod = nullptr;
+  double* d_turn_tab = nullptr;
   int n_pair = 0, n_up = 0;
   std::vector<void*> allocs;
   void* stage = nullptr;
@@ -618,7 +623,7 @@ static int reset_state(pedn_sim* s) {
 // table order.  Replica independent, so it is tabulated once per (step, product) on the host with the same binary64 operations.
 static int tabulate_pair_pod(pedn_sim* s) {
   const int T1 = s->v.T1, np = s->n_pair;
-  if (np == 0) return PEDN_OK;
+  if (np == 0 || s->d_turn_tab == nullptr) return PEDN_OK;
   std::vector<double> upod((size_t)s->h_upod_od.size());
   std::vector<double> table((size_t)T1 * np);
   for (int t = 0; t < T1; ++t) {
@@ -631,8 +636,19 @@ static int tabulate_pair_pod(pedn_sim* s) {
     }
     for (int q = 0; q < np; ++q) table[(size_t)t * np + q] = upod[s->h_pair_upod[q]];
   }
+  // turns whose products all have the constant probability 1: the fraction is the plain sequential sum of P(od | up)
+  const int nt = s->n_turns;
+  std::vector<double> ttab((size_t)T1 * std::max(nt, 1), 0.0);
+  for (int t = 0; t < T1; ++t)
+    for (int tn = 0; tn < nt; ++tn) {
+      if (!s->h_turn_mode[tn]) continue;
+      double acc = 0.0;
+      for (int q = s->h_turn_pair_ptr[tn]; q < s->h_turn_pair_ptr[tn + 1]; ++q) acc += 1.0 * table[(size_t)t * np + q];
+      ttab[(size_t)t * nt + tn] = acc;
+    }
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemcpy(s->d_pair_pod, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(s, hipMemcpy(s->d_turn_tab, ttab.data(), ttab.size() * sizeof(double), hipMemcpyHostToDevice));
   return PEDN_OK;
 }
 
@@ -774,6 +790,16 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     TRY(upload(s, ents.data(), ents.size(), &v.ents));
     TRY(upload(s, multi.data(), multi.size(), &v.grp_multi));
     TRY(upload(s, pconst.data(), pconst.size(), &v.pair_const));
+    s->h_pair_const = pconst;
+    s->h_turn_pair_ptr.assign(m->turn_pair_ptr, m->turn_pair_ptr + m->n_turns + 1);
+    s->h_turn_mode.assign(std::max(m->n_turns, 1), 0);
+    for (int tn = 0; tn < m->n_turns; ++tn) {
+      bool all_const = true;   // a turn without products is the constant 0
+      for (int q = m->turn_pair_ptr[tn]; q < m->turn_pair_ptr[tn + 1]; ++q) all_const = all_const && pconst[q];
+      s->h_turn_mode[tn] = all_const ? 1 : 0;
+    }
+    TRY(upload(s, s->h_turn_mode.data(), s->h_turn_mode.size(), &v.turn_mode));
+    v.n_turns = m->n_turns;
   }
   TRY(upload(s, m->grp_ent_ptr, m->n_grp + 1, &v.grp_ent_ptr));
   TRY(upload(s, m->grp_allphys, m->n_grp, &v.grp_allphys));
@@ -828,6 +854,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     TRY(dalloc(s, (size_t)std::max(m->n_pair, m->n_ent) * RS, &v.ent_p));
     TRY(dalloc(s, (size_t)m->n_pair * T1, &s->d_pair_pod));
     v.pair_pod = s->d_pair_pod;
+    TRY(dalloc(s, (size_t)std::max(m->n_turns, 1) * T1, &s->d_turn_tab));
+    v.turn_tab = s->d_turn_tab;
+    HIP_TRY(s, hipMemset(s->d_turn_tab, 0, (size_t)std::max(m->n_turns, 1) * T1 * sizeof(double)));
     TRY(dalloc(s, RS, &v.flags));
   }
   // initial widths, turning fractions, demand (broadcast to every replica)

@@ -114,10 +114,11 @@ struct RngKey {
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-    uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    // one 32x32->64 multiply (v_mad_u64_u32) per product instead of separate mul_hi / mul_lo
+    uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
