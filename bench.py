@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--network", default="melbourne")
     ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                    "multi-rank path on one GPU)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,33 +102,43 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_device:
+        local_rank = 0
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:          # launched by torch.distributed.run, also for N = 1
         import torch
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from pednstream_amd import NetworkEnvGenerator
     from pednstream_amd.flatten import flatten_network
 
-    R = args.replicas
+    from pednstream_amd.ensemble import shard
+
+    R = args.replicas                                          # weak scaling: R replicas on every GPU
+    offset, count = shard(R * world, world, rank)              # contiguous block of global replica ids
+    assert count == R
     gen = NetworkEnvGenerator(os.path.join(ROOT, "data"))
-    net = gen.create_network(args.network, verbose=False, n_replicas=R, replica_offset=rank * R, rng_seed=0,
+    net = gen.create_network(args.network, verbose=False, n_replicas=R, replica_offset=offset, rng_seed=0,
                              device=local_rank)
     T = net.simulation_steps
     e = net.engine()
     origins = list(net.origin_nodes)
     for r in range(R):
         for nid in origins:
-            e.set_demand(net.nodes[nid].index, replica_demand(T, rank * R + r), replica=r)
+            e.set_demand(net.nodes[nid].index, replica_demand(T, offset + r), replica=r)
     net._dirty_demand = set()
     e.synchronize()
     L = e.n_links
 
     def barrier():
+        e.synchronize()
         if dist is not None:
             import torch
             dist.barrier()
@@ -156,7 +169,7 @@ def main():
     wall = time.perf_counter() - t0
     if dist is not None:
         import torch
-        w = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        w = torch.tensor([wall], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     rc, _ = e.error_flags()
