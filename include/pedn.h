@@ -61,6 +61,10 @@ extern "C" {
 #define PEDN_W_FRONT 0
 #define PEDN_W_BACK 1
 #define PEDN_W_SEP 2
+/* 0/1 per (separator link, replica): the separator width is held as a numpy float64 scalar in the reference (it is after
+ * ActionApplier's np.clip, rl/builders.py:295), which makes `num_pedestrians / area` (link.py:136) a binary64 division
+ * rounded to float32 instead of a float32 division.  pedn_rl_apply_actions sets it; the plain setters clear it. */
+#define PEDN_W_SEP_NUMPY 3
 
 /* history fields; f64 fields 0..6 have n_links + n_vlinks columns for ids 0..3 (virtual links keep only those) */
 enum {
@@ -151,6 +155,8 @@ int pedn_get_turning_fractions(pedn_sim* sim, int32_t node, int32_t replica, dou
 int pedn_set_width(pedn_sim* sim, int32_t which, int32_t link, int32_t replica, double value);
 /* values[n_links][n_replicas] */
 int pedn_set_widths(pedn_sim* sim, int32_t which, const double* values);
+/* current widths -> values[n_links][n_replicas] (the device may have changed them through pedn_rl_apply_actions) */
+int pedn_get_widths(pedn_sim* sim, int32_t which, double* values);
 
 /* one step t in 1..T-1 for every replica; asynchronous */
 int pedn_step(pedn_sim* sim, int32_t t);
@@ -181,6 +187,40 @@ int pedn_profile_step(pedn_sim* sim, int32_t t, float ms[3]);
 
 /* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */
 int pedn_reset(pedn_sim* sim);
+
+/* ---- batched RL environment step around the hot path ------------------------------------------------
+ * Replaces, for every replica at once, the per-env Python glue of the reference's PettingZoo wrapper:
+ *   pedn_rl_apply_actions   ActionApplier.apply_all_actions / clip_*_action_value     rl/builders.py:264-352
+ *   pedn_rl_observe         ObservationBuilder.build_observation                       rl/builders.py:68-177 (+ :179-238 normalisation)
+ *                           PedNetParallelEnv._compute_rewards                          rl/pz_pednet_env.py:548-581
+ * Agents are listed in the reference's order (separators, then gaters; rl/discovery.py:121-123).  An action row holds,
+ * agent after agent, one width per separator and one width per outgoing link of a gater; an observation row holds 4
+ * features per separator and features_per_link x outdegree per gater (no padding, discovery.py:176-178). */
+typedef struct pedn_rl_desc {
+  int32_t n_agents;
+  const int32_t* agent_type;     /* [n_agents] 0 separator, 1 gater */
+  const int32_t* agent_link_ptr; /* [n_agents+1] */
+  const int32_t* agent_links;    /* gater: controlled outgoing links; separator: forward link, reverse link */
+  int32_t obs_mode;              /* 1..5 = "option1".."option5" (builders.py:47-58) */
+  int32_t normalize;             /* builders.py:179-238 */
+  int32_t reward_mode;           /* 0: as the reference runs (its `return` sits inside the agent loop, pz_pednet_env.py:581,
+                                       so only the first agent is ever rewarded); 1: every gater agent */
+  double max_delta_sep, max_delta_gate, min_sep; /* pz_pednet_env.py:84-86 */
+} pedn_rl_desc;
+
+/* validates the description and allocates the device buffers; returns the row lengths */
+int pedn_rl_configure(pedn_sim* sim, const pedn_rl_desc* desc, int32_t* n_actions, int32_t* n_obs);
+/* actions[n_replicas][n_actions] (binary64, widths in metres); on_device != 0: `actions` is a device pointer */
+int pedn_rl_apply_actions(pedn_sim* sim, const double* actions, int32_t on_device);
+/* observations and rewards of step t (after pedn_step(t)) into the device buffers; accumulate != 0 adds the rewards to
+ * the buffer (float32, like the reference's cumulative_rewards) instead of overwriting.  obs / rewards may be NULL;
+ * otherwise they receive host copies [n_replicas][n_obs] / [n_replicas][n_agents] (synchronises). */
+int pedn_rl_observe(pedn_sim* sim, int32_t t, int32_t accumulate, float* obs, float* rewards);
+/* apply -> action_gap x (pedn_step(t+k), observe) in one call (pz_pednet_env.py:195-254) */
+int pedn_rl_step(pedn_sim* sim, const double* actions, int32_t on_device, int32_t t, int32_t action_gap, float* obs,
+                 float* rewards);
+/* device buffers for zero-copy consumers: 0 actions (f64 [R][n_actions]), 1 observations (f32 [R][n_obs]), 2 rewards (f32 [R][n_agents]) */
+void* pedn_rl_device_ptr(pedn_sim* sim, int32_t which);
 
 /* Diagnostic: evaluate the device-side arithmetic primitives on the GPU so that tests can compare them bit for bit
  * with the oracle.  op 0: powf(a[i], b[i]) -> out (f32 in a/b/out as doubles); 1: exp(a[i]); 2: sqrt(a[i]);

@@ -100,6 +100,56 @@ def direct_case(case, adj, params, origin_nodes, destination_nodes=(), steps=Non
                                        "mutations": muts})
 
 
+def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_steps=150, seed=0, replica=0,
+            np_seed=20261003, action_seed=1):
+    """Config #5 caller: the reference's ActionApplier / ObservationBuilder / reward (rl/builders.py,
+    rl/pz_pednet_env.py:548-581) around network_loading, driven by seeded uniform actions in [-0.5, width + 0.5]
+    (so that both clip bounds and the per-step delta limit are exercised)."""
+    ref = rh.load_reference()
+    np.random.seed(np_seed)
+    net = ref["env"].NetworkEnvGenerator().create_network(name)
+    static = rh.dump_static(net)
+    env = rh.RefEnvShim(net, obs_mode=obs_mode, normalize_obs=normalize, action_gap=action_gap)
+    am = env.agent_manager
+    agents = env.possible_agents
+    spec = []
+    for a in agents:
+        if am.get_agent_type(a) == "sep":
+            f, r = am.get_separator_links(a)
+            spec.append({"id": a, "type": "sep", "links": [f.link_id, r.link_id]})
+        else:
+            spec.append({"id": a, "type": "gate", "links": [l.link_id for l in am.get_gater_outgoing_links(a)]})
+    rng = np.random.default_rng(action_seed)
+    acts, obs_l, rew_l, term_l = [], [], [], []
+    with rh.InjectedRNG(net, seed=seed, replica=replica) as inj:
+        for _ in range(env_steps):
+            actions = {}
+            row = []
+            for sp in spec:
+                if sp["type"] == "sep":
+                    w = net.links[tuple(int(x) for x in sp["links"][0].split("_"))].width
+                    a = rng.uniform(-0.5, w + 0.5, size=1).astype(np.float32)
+                else:
+                    ws = [net.links[tuple(int(x) for x in l.split("_"))].width for l in sp["links"]]
+                    a = np.array([rng.uniform(-0.5, w + 0.5) for w in ws], dtype=np.float32)
+                actions[sp["id"]] = a
+                row.extend(a.tolist())
+            obs, rew, term = env.step(actions)
+            acts.append(row)
+            obs_l.append(np.concatenate([np.asarray(obs[a], dtype=np.float32) for a in agents]))
+            rew_l.append([np.float32(rew[a]) for a in agents])
+            term_l.append(bool(list(term.values())[0]))
+    state = rh.dump_state(net, steps=env.sim_step)
+    extras = {"draws": dict(inj.draws), "steps_run": env.sim_step}
+    info = {"scenario": name, "seed": seed, "replica": replica, "mode": "philox", "np_seed": np_seed, "mutations": [],
+            "rl": {"obs_mode": obs_mode, "normalize": normalize, "action_gap": action_gap, "env_steps": env_steps, "agents": spec}}
+    state["rl_actions"] = np.array(acts, dtype=np.float32)
+    state["rl_obs"] = np.array(obs_l, dtype=np.float32)
+    state["rl_rewards"] = np.array(rew_l, dtype=np.float32)
+    state["rl_terminated"] = np.array(term_l)
+    save(case, static, state, extras, info)
+
+
 def kat_native():
     """G1 / G1b: the reference under its own numpy RNG (yaml seed 42 reseeds the global stream)."""
     ref = rh.load_reference()
@@ -200,6 +250,14 @@ CASES = {
                                           mutations=[(60, "separator_set", 1, 2, 0.9), (140, "separator_set", 2, 3, 2.4),
                                                      (200, "back_gate_set", 3, 4, 1.1)]),
 }
+CASES.update({
+    "rl_nine_opt3": lambda: rl_case("rl_nine_opt3", "nine_intersections", obs_mode="option3", env_steps=200),
+    "rl_nine_opt2n": lambda: rl_case("rl_nine_opt2n", "nine_intersections", obs_mode="option2", normalize=True, env_steps=120, action_seed=2),
+    "rl_nine_opt5g2": lambda: rl_case("rl_nine_opt5g2", "nine_intersections", obs_mode="option5", action_gap=2, env_steps=90, action_seed=3),
+    "rl_nine_opt4": lambda: rl_case("rl_nine_opt4", "nine_intersections", obs_mode="option4", env_steps=60, action_seed=4),
+    "rl_i45_opt3": lambda: rl_case("rl_i45_opt3", "45_intersections", obs_mode="option3", env_steps=200, action_seed=5),
+    "rl_corridor_opt1": lambda: rl_case("rl_corridor_opt1", "long_corridor", obs_mode="option1", env_steps=200, action_seed=6),
+})
 for _r in range(4):
     CASES[f"nine_replica{_r}"] = (lambda r=_r: scenario_case(
         f"nine_replica{r}", "nine_intersections", steps=160, seed=0, replica=r,

@@ -212,7 +212,7 @@ struct pedn_oracle {
   double* f64[7]; /* [Lall][T1] for 0..3, [L][T1] for 4..6 */
   float* f32[6];  /* [L][T1]: tt, att, N, k, v, lf */
   float* rsum;    /* [L] */
-  double *front, *back, *sepw; /* [L] */
+  double *front, *back, *sepw, *sepnp; /* [L]; sepnp: separator width is a numpy float64 scalar (see PEDN_W_SEP_NUMPY) */
   double* tf;                  /* [n_turns] */
   double* demand;              /* [n_demand][T1] */
   double* od_w;                /* [n_od][T1] */
@@ -301,6 +301,8 @@ pedn_oracle* pedn_oracle_create(const pedn_model_desc* md, uint64_t seed, int32_
   o->front = (double*)own(o, md->front_gate0, sizeof(double) * L);
   o->back = (double*)own(o, md->back_gate0, sizeof(double) * L);
   o->sepw = (double*)own(o, md->sep_width0, sizeof(double) * L);
+  o->sepnp = (double*)own(o, NULL, sizeof(double) * L);
+  memset(o->sepnp, 0, sizeof(double) * L);
   o->tf = (double*)own(o, md->tf_init, sizeof(double) * m->n_turns);
   o->demand = (double*)own(o, md->demand, sizeof(double) * m->n_demand * T1);
   o->od_w = (double*)own(o, md->od_w, sizeof(double) * m->n_od * T1);
@@ -558,7 +560,8 @@ static void link_density(pedn_oracle* o, int l, int t) { /* link.py:133-136 */
   float* N = G(o, G_N, l);
   double d = H(o, F_IN, l)[t] - H(o, F_OUT, l)[t];
   N[t] = (float)((double)N[t - 1] + d);
-  G(o, G_K, l)[t] = N[t] / (float)area_of(o, l);
+  if (o->m.link_sep[l] && o->sepnp[l] != 0.0) G(o, G_K, l)[t] = (float)((double)N[t] / area_of(o, l)); /* np.float32 / np.float64 */
+  else G(o, G_K, l)[t] = N[t] / (float)area_of(o, l);
 }
 
 static void link_speed(pedn_oracle* o, int l, int t) { /* link.py:141-188 + functions.py:112-134 */
@@ -642,7 +645,7 @@ void pedn_oracle_set_od_weights(pedn_oracle* o, int od, const double* v, int n) 
   memcpy(o->od_w + (size_t)od * o->T1, v, sizeof(double) * (size_t)(n < o->T1 ? n : o->T1));
 }
 void pedn_oracle_set_width(pedn_oracle* o, int which, int link, double v) {
-  (which == PEDN_W_FRONT ? o->front : which == PEDN_W_BACK ? o->back : o->sepw)[link] = v;
+  (which == PEDN_W_FRONT ? o->front : which == PEDN_W_BACK ? o->back : which == PEDN_W_SEP ? o->sepw : o->sepnp)[link] = v;
 }
 void pedn_oracle_set_tf(pedn_oracle* o, int node, const double* tf, int n) {
   memcpy(o->tf + o->m.node_turn_ptr[node], tf, sizeof(double) * (size_t)n);

@@ -264,3 +264,69 @@ def run_reference(name, steps=None, seed=0, replica=0, mode="philox", mutate=Non
     if record_tf:
         extras["tf_hist"] = {k: np.stack(v) for k, v in tf_hist.items()}
     return network, static, state, extras
+
+
+# ------------------------------------------------------------------------------------------------ RL caller (config #5)
+def load_reference_rl():
+    """The reference's RL glue.  `rl/__init__.py` imports pettingzoo/gymnasium, which this image lacks, so the package
+    initialiser is bypassed: a bare package object stands in for `rl` and the REAL modules rl/discovery.py and
+    rl/builders.py (numpy only) are imported under it.  The env class itself (rl/pz_pednet_env.py) cannot be imported;
+    its two pure functions `_compute_rewards` (:548-581) and `_check_terminations` (:583-624) are compiled from the
+    reference's own source text, unmodified, and called on a small stand-in carrying the attributes they read."""
+    if "rl_mods" in _loaded:
+        return _loaded["rl_mods"]
+    load_reference()
+    import ast
+    import importlib
+    import types
+
+    if "rl" not in sys.modules:
+        pkg = types.ModuleType("rl")
+        pkg.__path__ = [os.path.join(REF_ROOT, "rl")]
+        sys.modules["rl"] = pkg
+    discovery = importlib.import_module("rl.discovery")
+    builders = importlib.import_module("rl.builders")
+    path = os.path.join(REF_ROOT, "rl", "pz_pednet_env.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    wanted = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.ClassDef) and node.name == "PedNetParallelEnv":
+            for item in node.body:
+                if isinstance(item, ast.FunctionDef) and item.name in ("_compute_rewards", "_check_terminations"):
+                    mod = ast.Module(body=[item], type_ignores=[])
+                    ns = {"np": np, "Dict": dict}
+                    exec(compile(mod, path, "exec"), ns)
+                    wanted[item.name] = ns[item.name]
+    _loaded["rl_mods"] = {"discovery": discovery, "builders": builders, **wanted}
+    return _loaded["rl_mods"]
+
+
+class RefEnvShim:
+    """State the extracted `_compute_rewards` / `_check_terminations` read (pz_pednet_env.py:49-116)."""
+
+    def __init__(self, network, obs_mode="option3", normalize_obs=False, action_gap=1):
+        rl = load_reference_rl()
+        self.network = network
+        self.sim_step = 1
+        self.simulation_steps = network.params["simulation_steps"]
+        self.agent_manager = rl["discovery"].AgentManager(network)
+        self.possible_agents = self.agent_manager.get_all_agent_ids()
+        self.obs_builder = rl["builders"].ObservationBuilder(network, self.agent_manager, normalize_obs, obs_mode)
+        ut = network.params["unit_time"]
+        self.action_applier = rl["builders"].ActionApplier(network, self.agent_manager, 0.25 * ut, 0.25 * ut, 1.5)
+        self._action_gap = action_gap
+        self._rl = rl
+
+    def step(self, actions):
+        """pz_pednet_env.py:195-254 restated around the real components."""
+        if len(actions) > 0:
+            self.action_applier.apply_all_actions(actions)
+        cumulative = {a: 0.0 for a in self.possible_agents}
+        for _ in range(self._action_gap):
+            self.network.network_loading(self.sim_step)
+            obs = {a: self.obs_builder.build_observation(a, self.sim_step) for a in self.possible_agents}
+            for a, r in self._rl["_compute_rewards"](self).items():
+                cumulative[a] += r
+            term = self._rl["_check_terminations"](self)
+            self.sim_step += 1
+        return obs, cumulative, term

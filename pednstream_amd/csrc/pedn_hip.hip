@@ -54,7 +54,7 @@ struct DevView {
   double* f64[7];
   float* f32[6];
   float* rsum;
-  double *front, *back, *sepw, *tf, *demand, *ent_p;
+  double *front, *back, *sepw, *sepnp, *tf, *demand, *ent_p;
   const double* od_w;
   uint32_t* flags;
   const LinkP* lp;
@@ -467,14 +467,115 @@ __global__ __launch_bounds__(256, 8) void link_kernel(DevView v, int t) {
   float nb = (float)((double)v.f32[G_N][at(t - 1, b, L, RS, r)] + db);
   double wa = Pa.sep ? v.sepw[(size_t)a * RS + r] : Pa.width;
   double wb = Pb.sep ? v.sepw[(size_t)b * RS + r] : Pb.width;
-  float ka = na / (float)(Pa.length * wa);
-  float kb = nb / (float)(Pb.length * wb);
+  // a separator width held as np.float64 turns the division into binary64 (PEDN_W_SEP_NUMPY)
+  float ka = (Pa.sep && v.sepnp[(size_t)a * RS + r] != 0.0) ? (float)((double)na / (Pa.length * wa)) : na / (float)(Pa.length * wa);
+  float kb = (Pb.sep && v.sepnp[(size_t)b * RS + r] != 0.0) ? (float)((double)nb / (Pb.length * wb)) : nb / (float)(Pb.length * wb);
   v.f32[G_N][at(t, a, L, RS, r)] = na;
   v.f32[G_N][at(t, b, L, RS, r)] = nb;
   v.f32[G_K][at(t, a, L, RS, r)] = ka;
   v.f32[G_K][at(t, b, L, RS, r)] = kb;
   speed_update(v, Pa, a, t, r, ka, kb, Pa.sep ? wa : v.back[(size_t)a * RS + r]);
   speed_update(v, Pb, b, t, r, kb, ka, Pb.sep ? wb : v.back[(size_t)b * RS + r]);
+}
+
+// ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------
+struct RlView {
+  const int32_t *agent_type, *agent_link_ptr, *agent_links, *agent_act_off, *agent_obs_off;
+  const int32_t *slot_agent, *slot_idx;  // action slot -> (agent, position in the agent's link list)
+  double* actions;                        // [R][A]
+  float *obs, *rew;                       // [R][O], [R][n_agents]
+  int32_t n_agents, A, O, obs_mode, normalize, reward_mode, fpl;
+  double max_delta_sep, max_delta_gate, min_sep;
+};
+
+__device__ __forceinline__ double clip_d(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }  // np.clip
+
+// ActionApplier (builders.py:281-352): one lane per (action slot, replica)
+__global__ void rl_apply_kernel(DevView v, RlView q) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int a = (int)(gid / (size_t)v.RS), r = (int)(gid % (size_t)v.RS);
+  if (a >= q.A || r >= v.R) return;
+  const int ag = q.slot_agent[a], i = q.slot_idx[a];
+  const int l = q.agent_links[q.agent_link_ptr[ag] + i];
+  const LinkP P = v.lp[l];
+  double x = q.actions[(size_t)r * q.A + a];
+  if (q.agent_type[ag] == 0) {  // separator: clip_separator_action_value + Separator.separator_width setter (link.py:462-478)
+    const double cur = v.sepw[(size_t)l * v.RS + r];
+    if (fabs(x - cur) > q.max_delta_sep) x = cur + clip_d(x - cur, -q.max_delta_sep, q.max_delta_sep);
+    x = clip_d(x, q.min_sep, P.width - q.min_sep);
+    const double other = P.width - x;
+    v.sepnp[(size_t)l * v.RS + r] = 1.0; v.sepnp[(size_t)P.rev * v.RS + r] = 1.0;  // np.clip returns np.float64
+    v.sepw[(size_t)l * v.RS + r] = x; v.front[(size_t)l * v.RS + r] = x; v.back[(size_t)l * v.RS + r] = x;
+    v.sepw[(size_t)P.rev * v.RS + r] = other; v.front[(size_t)P.rev * v.RS + r] = other; v.back[(size_t)P.rev * v.RS + r] = other;
+  } else {  // gater: clip_gater_action_value + back_gate_width setter (link.py:121-126)
+    const double cur = v.back[(size_t)l * v.RS + r];
+    if (fabs(x - cur) > q.max_delta_gate) x = cur + clip_d(x - cur, -q.max_delta_gate, q.max_delta_gate);
+    x = clip_d(x, 0.0, P.width);
+    v.back[(size_t)l * v.RS + r] = x;
+    v.front[(size_t)P.rev * v.RS + r] = x;
+  }
+}
+
+// ObservationBuilder + _compute_rewards: one lane per (agent, replica)
+__global__ void rl_observe_kernel(DevView v, RlView q, int t, int accumulate) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int ag = (int)(gid / (size_t)v.RS), r = (int)(gid % (size_t)v.RS);
+  if (ag >= q.n_agents || r >= v.R) return;
+  const int RS = v.RS, L = v.L, Lall = v.Lall;
+  const int la = q.agent_link_ptr[ag], n = q.agent_link_ptr[ag + 1] - la;
+  float* o = q.obs + (size_t)r * q.O + q.agent_obs_off[ag];
+  float reward = 0.0f;
+  bool rewarded = false;
+  if (q.agent_type[ag] == 0) {  // builders.py:87-117
+    const int f = q.agent_links[la], b = q.agent_links[la + 1];
+    float x[4] = {(float)v.f64[F_IN][at(t, f, Lall, RS, r)], (float)v.f64[F_OUT][at(t, f, Lall, RS, r)],
+                  (float)v.f64[F_IN][at(t, b, Lall, RS, r)], (float)v.f64[F_OUT][at(t, b, Lall, RS, r)]};
+    for (int k = 0; k < 4; ++k) {
+      if (q.normalize && (q.obs_mode == 1 || q.obs_mode == 2)) x[k] = x[k] / 20.0f;  // builders.py:183-188
+      o[k] = x[k];
+    }
+  } else {  // builders.py:119-177
+    float dens_sum = 0.0f, lr = 0.0f;
+    float dens_all[PEDN_MAX_DEGREE];
+    for (int i = 0; i < n; ++i) {
+      const int l = q.agent_links[la + i];
+      const LinkP P = v.lp[l];
+      const float in_l = (float)v.f64[F_IN][at(t, l, Lall, RS, r)], out_l = (float)v.f64[F_OUT][at(t, l, Lall, RS, r)];
+      const float in_r = (float)v.f64[F_IN][at(t, P.rev, Lall, RS, r)], out_r = (float)v.f64[F_OUT][at(t, P.rev, Lall, RS, r)];
+      const float dens = dens_at(v, P, l, t, r);
+      const float gate = (float)v.back[(size_t)l * RS + r];
+      float* oi = o + i * q.fpl;
+      switch (q.obs_mode) {
+        case 1: oi[0] = in_l; oi[1] = out_r; oi[2] = gate; break;
+        case 2: oi[0] = in_l; oi[1] = out_r; oi[2] = dens; oi[3] = gate; break;
+        case 3: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = gate; break;
+        case 4: oi[0] = dens / (float)P.kj; oi[1] = gate; break;
+        default: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = v.f32[G_V][at(t, l, L, RS, r)]; oi[5] = dens; oi[6] = gate;
+      }
+      if (q.normalize) {  // builders.py:204-238, applied literally
+        if (q.obs_mode == 1 || q.obs_mode == 2) { oi[0] = oi[0] / 20.0f; oi[1] = oi[1] / 20.0f; }
+        else if (q.obs_mode == 3) { oi[0] = oi[0] / 6.0f; oi[1] = oi[1] / 20.0f; oi[2] = oi[2] / 20.0f; }
+      }
+      // reward terms (pz_pednet_env.py:557-570), float32 throughout
+      const float tsum = v.f32[G_TT][at(t, l, L, RS, r)] + v.f32[G_TT][at(t, P.rev, L, RS, r)];
+      lr = (i == 0) ? 0.0f - tsum : lr - tsum;
+      if (dens > 4.0f) lr = lr - 10.0f * (dens - (float)P.kc);
+      if (i < PEDN_MAX_DEGREE) dens_all[i] = dens;
+      dens_sum = (i == 0) ? dens : dens_sum + dens;
+    }
+    if (n > 1) {  // variance penalty, :572-577 (np.mean of float32: sequential float32 sum / n)
+      const float avg = dens_sum / (float)n;
+      float dsum = 0.0f;
+      for (int i = 0; i < n && i < PEDN_MAX_DEGREE; ++i) { float d = fabsf(dens_all[i] - avg); dsum = (i == 0) ? d : dsum + d; }
+      lr = lr - 10.0f * (dsum / (float)n);
+    }
+    reward = lr;
+    rewarded = true;
+  }
+  if (q.reward_mode == 0 && ag != 0) rewarded = false;  // the reference returns after the first agent (:581)
+  float* rw = q.rew + (size_t)r * q.n_agents + ag;
+  const float add = rewarded ? reward : 0.0f;
+  *rw = (accumulate && rewarded) ? *rw + add : (accumulate ? *rw : add);
 }
 
 // ---- state initialisation / host <-> device helpers ---------------------------------------------------------
@@ -554,6 +655,8 @@ struct pedn_sim {
   std::vector<int32_t> h_turn_pair_ptr, h_pair_const, h_turn_mode;
   double* d_pair_pod = nullptr;
   double* d_turn_tab = nullptr;
+  RlView rl{};
+  bool rl_ready = false;
   int n_pair = 0, n_up = 0;
   std::vector<void*> allocs;
   void* stage = nullptr;
@@ -849,6 +952,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     TRY(dalloc(s, (size_t)L * RS, &v.front));
     TRY(dalloc(s, (size_t)L * RS, &v.back));
     TRY(dalloc(s, (size_t)L * RS, &v.sepw));
+    TRY(dalloc(s, (size_t)L * RS, &v.sepnp));
+    HIP_TRY(s, hipMemset(v.sepnp, 0, std::max<size_t>((size_t)L * RS, 1) * sizeof(double)));
     TRY(dalloc(s, (size_t)m->n_turns * RS, &v.tf));
     TRY(dalloc(s, (size_t)m->n_demand * T1 * RS, &v.demand));
     TRY(dalloc(s, (size_t)std::max(m->n_pair, m->n_ent) * RS, &v.ent_p));
@@ -981,17 +1086,17 @@ int pedn_get_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, doubl
 
 int pedn_set_width(pedn_sim* s, int32_t which, int32_t link, int32_t replica, double value) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
-  if (link < 0 || link >= s->v.L || which < 0 || which > 2) return fail(s, PEDN_E_ARG, "link or selector out of range");
-  double* dst = which == PEDN_W_FRONT ? s->v.front : which == PEDN_W_BACK ? s->v.back : s->v.sepw;
+  if (link < 0 || link >= s->v.L || which < 0 || which > 3) return fail(s, PEDN_E_ARG, "link or selector out of range");
+  double* dst = which == PEDN_W_FRONT ? s->v.front : which == PEDN_W_BACK ? s->v.back : which == PEDN_W_SEP ? s->v.sepw : s->v.sepnp;
   return push_rows(s, dst, &value, 1, (size_t)link, 1, replica);
 }
 
 int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
   if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
-  if (which < 0 || which > 2) return fail(s, PEDN_E_ARG, "selector out of range");
+  if (which < 0 || which > 3) return fail(s, PEDN_E_ARG, "selector out of range");
   DevView& v = s->v;
   if (v.L == 0) return PEDN_OK;
-  double* dst = which == PEDN_W_FRONT ? v.front : which == PEDN_W_BACK ? v.back : v.sepw;
+  double* dst = which == PEDN_W_FRONT ? v.front : which == PEDN_W_BACK ? v.back : which == PEDN_W_SEP ? v.sepw : v.sepnp;
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   size_t bytes = (size_t)v.L * v.R * 8;
@@ -1002,6 +1107,18 @@ int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst, (const double*)s->stage, v.L,
                      (size_t)0, (size_t)1, v.RS, 0, v.R, 1, v.R);
   HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
+int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
+  if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
+  if (which < 0 || which > 3) return fail(s, PEDN_E_ARG, "selector out of range");
+  DevView& v = s->v;
+  if (v.L == 0) return PEDN_OK;
+  const double* src = which == PEDN_W_FRONT ? v.front : which == PEDN_W_BACK ? v.back : which == PEDN_W_SEP ? v.sepw : v.sepnp;
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipMemcpy2D(values, (size_t)v.R * 8, src, (size_t)v.RS * 8, (size_t)v.R * 8, v.L, hipMemcpyDeviceToHost));
   return PEDN_OK;
 }
 
@@ -1137,6 +1254,111 @@ int pedn_timer_end(pedn_sim* s, float* ms) {
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
   return PEDN_OK;
+}
+
+int pedn_rl_configure(pedn_sim* s, const pedn_rl_desc* d, int32_t* n_actions, int32_t* n_obs) {
+  if (!s || !d) return fail(s, PEDN_E_ARG, "null argument");
+  if (d->n_agents < 1) return fail(s, PEDN_E_ARG, "no agents");
+  if (d->obs_mode < 1 || d->obs_mode > 5) return fail(s, PEDN_E_ARG, "obs_mode must be 1..5");
+  HIP_TRY(s, hipSetDevice(s->device));
+  static const int fpl_of[6] = {0, 3, 4, 5, 2, 7};  // builders.py:47-58
+  const int fpl = fpl_of[d->obs_mode];
+  DevView& v = s->v;
+  std::vector<int32_t> act_off(d->n_agents), obs_off(d->n_agents), slot_agent, slot_idx;
+  int A = 0, O = 0;
+  for (int a = 0; a < d->n_agents; ++a) {
+    const int n = d->agent_link_ptr[a + 1] - d->agent_link_ptr[a];
+    act_off[a] = A; obs_off[a] = O;
+    for (int k = d->agent_link_ptr[a]; k < d->agent_link_ptr[a + 1]; ++k) {
+      int l = d->agent_links[k];
+      if (l < 0 || l >= v.L) return fail(s, PEDN_E_ARG, "agent link out of range");
+    }
+    if (d->agent_type[a] == 0) {
+      if (n != 2) return fail(s, PEDN_E_ARG, "separator agent needs (forward, reverse)");
+      if (d->normalize && (d->obs_mode == 3 || d->obs_mode == 4))
+        return fail(s, PEDN_E_ARG, "normalised separator observations index out of range for option3/option4 (IndexError in the reference, builders.py:189-198)");
+      slot_agent.push_back(a); slot_idx.push_back(0);
+      A += 1; O += 4;
+    } else if (d->agent_type[a] == 1) {
+      if (n < 1 || n > PEDN_MAX_DEGREE) return fail(s, PEDN_E_ARG, "gater outdegree outside 1..8");
+      if (d->normalize && d->obs_mode == 4)
+        return fail(s, PEDN_E_ARG, "normalised gater observations index out of range for option4 (IndexError in the reference, builders.py:229-236)");
+      for (int i = 0; i < n; ++i) { slot_agent.push_back(a); slot_idx.push_back(i); }
+      A += n; O += n * fpl;
+    } else return fail(s, PEDN_E_ARG, "agent_type must be 0 or 1");
+  }
+  RlView& q = s->rl;
+  int rc;
+#define UP(src, n, dst) if ((rc = upload(s, src, n, dst)) != PEDN_OK) return rc
+  UP(d->agent_type, (size_t)d->n_agents, &q.agent_type);
+  UP(d->agent_link_ptr, (size_t)d->n_agents + 1, &q.agent_link_ptr);
+  UP(d->agent_links, (size_t)d->agent_link_ptr[d->n_agents], &q.agent_links);
+  UP(act_off.data(), act_off.size(), &q.agent_act_off);
+  UP(obs_off.data(), obs_off.size(), &q.agent_obs_off);
+  UP(slot_agent.data(), slot_agent.size(), &q.slot_agent);
+  UP(slot_idx.data(), slot_idx.size(), &q.slot_idx);
+#undef UP
+  if ((rc = dalloc(s, (size_t)v.R * A, &q.actions)) != PEDN_OK) return rc;
+  if ((rc = dalloc(s, (size_t)v.R * O, &q.obs)) != PEDN_OK) return rc;
+  if ((rc = dalloc(s, (size_t)v.R * d->n_agents, &q.rew)) != PEDN_OK) return rc;
+  HIP_TRY(s, hipMemset(q.obs, 0, (size_t)v.R * O * sizeof(float)));
+  HIP_TRY(s, hipMemset(q.rew, 0, (size_t)v.R * d->n_agents * sizeof(float)));
+  q.n_agents = d->n_agents; q.A = A; q.O = O; q.obs_mode = d->obs_mode; q.normalize = d->normalize; q.reward_mode = d->reward_mode;
+  q.fpl = fpl; q.max_delta_sep = d->max_delta_sep; q.max_delta_gate = d->max_delta_gate; q.min_sep = d->min_sep;
+  s->rl_ready = true;
+  if (n_actions) *n_actions = A;
+  if (n_obs) *n_obs = O;
+  return PEDN_OK;
+}
+
+int pedn_rl_apply_actions(pedn_sim* s, const double* actions, int32_t on_device) {
+  if (!s || !actions) return fail(s, PEDN_E_ARG, "null argument");
+  if (!s->rl_ready) return fail(s, PEDN_E_ARG, "pedn_rl_configure has not been called");
+  HIP_TRY(s, hipSetDevice(s->device));
+  DevView& v = s->v;
+  RlView& q = s->rl;
+  const size_t bytes = (size_t)v.R * q.A * sizeof(double);
+  if (actions != q.actions)
+    HIP_TRY(s, hipMemcpyAsync(q.actions, actions, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->stream));
+  size_t n = (size_t)q.A * v.RS;
+  hipLaunchKernelGGL(rl_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, q);
+  HIP_TRY(s, hipGetLastError());
+  if (!on_device) HIP_TRY(s, hipStreamSynchronize(s->stream));  // the host buffer is borrowed for the call only
+  return PEDN_OK;
+}
+
+int pedn_rl_observe(pedn_sim* s, int32_t t, int32_t accumulate, float* obs, float* rewards) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (!s->rl_ready) return fail(s, PEDN_E_ARG, "pedn_rl_configure has not been called");
+  if (t < 0 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 0..T");
+  HIP_TRY(s, hipSetDevice(s->device));
+  DevView& v = s->v;
+  RlView& q = s->rl;
+  size_t n = (size_t)q.n_agents * v.RS;
+  hipLaunchKernelGGL(rl_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, q, t, accumulate);
+  HIP_TRY(s, hipGetLastError());
+  if (obs) HIP_TRY(s, hipMemcpyAsync(obs, q.obs, (size_t)v.R * q.O * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  if (rewards) HIP_TRY(s, hipMemcpyAsync(rewards, q.rew, (size_t)v.R * q.n_agents * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  if (obs || rewards) HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return PEDN_OK;
+}
+
+int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t t, int32_t action_gap, float* obs, float* rewards) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (action_gap < 1 || t < 1 || t + action_gap - 1 > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
+  int rc = PEDN_OK;
+  if (actions && (rc = pedn_rl_apply_actions(s, actions, on_device)) != PEDN_OK) return rc;
+  for (int k = 0; k < action_gap; ++k) {
+    launch_step(s, t + k);
+    const bool last = k == action_gap - 1;
+    if ((rc = pedn_rl_observe(s, t + k, k > 0, last ? obs : nullptr, last ? rewards : nullptr)) != PEDN_OK) return rc;
+  }
+  return PEDN_OK;
+}
+
+void* pedn_rl_device_ptr(pedn_sim* s, int32_t which) {
+  if (!s || !s->rl_ready) return nullptr;
+  return which == 0 ? (void*)s->rl.actions : which == 1 ? (void*)s->rl.obs : which == 2 ? (void*)s->rl.rew : nullptr;
 }
 
 int pedn_device_math(int32_t device, int32_t op, int32_t n, const double* a, const double* b, uint64_t seed, double* out) {

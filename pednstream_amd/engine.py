@@ -47,6 +47,14 @@ class ModelDesc(C.Structure):
     ]
 
 
+class RlDesc(C.Structure):
+    """Mirror of ``pedn_rl_desc`` (include/pedn.h)."""
+
+    _fields_ = [("n_agents", C.c_int32), ("agent_type", _I32P), ("agent_link_ptr", _I32P), ("agent_links", _I32P),
+                ("obs_mode", C.c_int32), ("normalize", C.c_int32), ("reward_mode", C.c_int32),
+                ("max_delta_sep", C.c_double), ("max_delta_gate", C.c_double), ("min_sep", C.c_double)]
+
+
 _PTR_TYPES = {_I32P: np.int32, _F64P: np.float64, _F32P: np.float32}
 
 
@@ -87,6 +95,7 @@ def _load():
         "pedn_get_turning_fractions": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
         "pedn_set_width": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
         "pedn_set_widths": (C.c_int, [P, C.c_int32, _F64P]),
+        "pedn_get_widths": (C.c_int, [P, C.c_int32, _F64P]),
         "pedn_step": (C.c_int, [P, C.c_int32]),
         "pedn_run": (C.c_int, [P, C.c_int32, C.c_int32]),
         "pedn_synchronize": (C.c_int, [P]),
@@ -98,6 +107,11 @@ def _load():
         "pedn_timer_end": (C.c_int, [P, C.POINTER(C.c_float)]),
         "pedn_reset": (C.c_int, [P]),
         "pedn_profile_step": (C.c_int, [P, C.c_int32, C.POINTER(C.c_float)]),
+        "pedn_rl_configure": (C.c_int, [P, C.POINTER(RlDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "pedn_rl_apply_actions": (C.c_int, [P, C.c_void_p, C.c_int32]),
+        "pedn_rl_observe": (C.c_int, [P, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+        "pedn_rl_step": (C.c_int, [P, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+        "pedn_rl_device_ptr": (C.c_void_p, [P, C.c_int32]),
         "pedn_device_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _F64P, _F64P, C.c_uint64, _F64P]),
     }
     for name, (res, args) in sig.items():
@@ -121,7 +135,8 @@ def lib():
 EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
-           "pedn_device_ptr", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step"]
+           "pedn_device_ptr", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_rl_configure",
+           "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths"]
 
 
 class ModelError(RuntimeError):
@@ -205,6 +220,11 @@ class Engine:
         assert v.shape == (self.n_links, self.n_replicas)
         self._ck(self._lib.pedn_set_widths(self._h, int(which), v.ctypes.data_as(_F64P)))
 
+    def get_widths(self, which):
+        out = np.empty((self.n_links, self.n_replicas), dtype=np.float64)
+        self._ck(self._lib.pedn_get_widths(self._h, int(which), out.ctypes.data_as(_F64P)))
+        return out
+
     # -- stepping
     def step(self, t):
         self._ck(self._lib.pedn_step(self._h, int(t)))
@@ -243,6 +263,51 @@ class Engine:
         ms = (C.c_float * 3)()
         self._ck(self._lib.pedn_profile_step(self._h, int(t), ms))
         return tuple(float(x) for x in ms)
+
+    # -- batched RL glue
+    def rl_configure(self, agent_type, agent_link_ptr, agent_links, obs_mode, normalize, reward_mode, max_delta_sep,
+                     max_delta_gate, min_sep):
+        keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (agent_type, agent_link_ptr, agent_links)]
+        d = RlDesc(len(keep[0]), keep[0].ctypes.data_as(_I32P), keep[1].ctypes.data_as(_I32P), keep[2].ctypes.data_as(_I32P),
+                   int(obs_mode), int(bool(normalize)), int(reward_mode), float(max_delta_sep), float(max_delta_gate), float(min_sep))
+        na, no = C.c_int32(), C.c_int32()
+        rc = self._lib.pedn_rl_configure(self._h, C.byref(d), C.byref(na), C.byref(no))
+        if rc < 0:
+            msg = self._lib.pedn_last_error(self._h).decode()
+            raise (IndexError if "IndexError" in msg else ValueError)(msg)
+        self.rl_n_agents, self.rl_n_actions, self.rl_n_obs = len(keep[0]), na.value, no.value
+        return na.value, no.value
+
+    def rl_apply_actions(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        assert a.shape == (self.n_replicas, self.rl_n_actions), a.shape
+        self._ck(self._lib.pedn_rl_apply_actions(self._h, a.ctypes.data_as(C.c_void_p), 0))
+
+    def rl_observe(self, t, accumulate=False, fetch=True):
+        if not fetch:
+            self._ck(self._lib.pedn_rl_observe(self._h, int(t), int(accumulate), None, None))
+            return None, None
+        obs = np.empty((self.n_replicas, self.rl_n_obs), dtype=np.float32)
+        rew = np.empty((self.n_replicas, self.rl_n_agents), dtype=np.float32)
+        self._ck(self._lib.pedn_rl_observe(self._h, int(t), int(accumulate), obs.ctypes.data_as(C.c_void_p), rew.ctypes.data_as(C.c_void_p)))
+        return obs, rew
+
+    def rl_step(self, actions, t, action_gap=1, fetch=True):
+        """apply -> action_gap x (step, observe); returns host copies of the last observations and the summed rewards."""
+        a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float64)
+        if a is not None:
+            assert a.shape == (self.n_replicas, self.rl_n_actions), a.shape
+        obs = rew = None
+        if fetch:
+            obs = np.empty((self.n_replicas, self.rl_n_obs), dtype=np.float32)
+            rew = np.empty((self.n_replicas, self.rl_n_agents), dtype=np.float32)
+        self._ck(self._lib.pedn_rl_step(self._h, None if a is None else a.ctypes.data_as(C.c_void_p), 0, int(t), int(action_gap),
+                                        None if obs is None else obs.ctypes.data_as(C.c_void_p),
+                                        None if rew is None else rew.ctypes.data_as(C.c_void_p)))
+        return obs, rew
+
+    def rl_device_ptr(self, which):
+        return self._lib.pedn_rl_device_ptr(self._h, int(which))
 
     def timer_begin(self):
         self._ck(self._lib.pedn_timer_begin(self._h))

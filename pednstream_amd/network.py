@@ -198,11 +198,15 @@ class LinkView(BaseLinkView):
         if not self.is_separator:
             raise AttributeError("separator_width is only defined for separator links")
         net = self._net
+        # a numpy float64 width makes density = N / area a binary64 division in the reference (link.py:136,456)
+        is_np = 1.0 if isinstance(value, np.floating) else 0.0
         for which in ("sep", "front", "back"):
             net._set_width(which, self.index, value)
+        net._set_width("sepnp", self.index, is_np)
         if self.reverse_link is not None:
             for which in ("sep", "front", "back"):
                 net._set_width(which, self.reverse_link.index, self._width - value)
+            net._set_width("sepnp", self.reverse_link.index, is_np)
 
     _front_gate_width = property(lambda self: self.front_gate_width)
     _back_gate_width = property(lambda self: self.back_gate_width)
@@ -483,7 +487,7 @@ class Network:
         L, R = self.n_links, self.n_replicas
         init = np.array([l._init_widths for l in self._link_list], dtype=np.float64).reshape(L, 3)
         self._widths = {"front": np.repeat(init[:, 0:1], R, axis=1), "back": np.repeat(init[:, 1:2], R, axis=1),
-                        "sep": np.repeat(init[:, 2:3], R, axis=1)}
+                        "sep": np.repeat(init[:, 2:3], R, axis=1), "sepnp": np.zeros((L, R))}
         self._tf_host = {}     # node index -> [edge_num, R] array, for values imposed before the engine exists
 
     # ------------------------------------------------------------------------------------------ engine plumbing
@@ -499,7 +503,7 @@ class Network:
             self._engine = _engine.Engine(flatten_network(self), n_replicas=self.n_replicas,
                                           replica_offset=self.replica_offset, seed=self.rng_seed,
                                           mode=self.rng_mode, device=self.device)
-            for which, code in (("front", 0), ("back", 1), ("sep", 2)):
+            for which, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3)):
                 self._engine.set_widths(code, self._widths[which])
             for nidx, tf in self._tf_host.items():
                 self._engine.set_turning_fractions(nidx, tf)
@@ -539,11 +543,20 @@ class Network:
             return col[t]
         return self._flush().read_element(fid, link_index, self._replica_index(), t)
 
+    def _refresh_widths(self):
+        """Pull the widths back after the device changed them (batched RL actions)."""
+        if getattr(self, "_widths_stale", False) and self._engine is not None:
+            for which, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3)):
+                self._widths[which] = self._engine.get_widths(code)
+        self._widths_stale = False
+
     def _get_width(self, which, link_index):
+        self._refresh_widths()
         return float(self._widths[which][link_index, self._replica_index()])
 
     def _set_width(self, which, link_index, value):
-        code = {"front": 0, "back": 1, "sep": 2}[which]
+        code = {"front": 0, "back": 1, "sep": 2, "sepnp": 3}[which]
+        self._refresh_widths()
         if self._scope is None:
             self._widths[which][link_index, :] = value
         else:

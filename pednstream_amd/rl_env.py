@@ -1,0 +1,234 @@
+"""Vectorised RL environment around the hot path (BASELINE config #5).
+
+Host mirror of the reference's multi-agent glue, with the per-env Python loops replaced by device kernels that act on
+every replica at once:
+
+  AgentManager     agent discovery from the controller configuration            rl/discovery.py:20-178
+  VecPedNetEnv     n_envs independent copies of one scenario; step(actions[B, A]) ->
+                   (obs[B, O] float32, rewards[B, n_agents] float32, terminated, truncated, info)
+                   = ActionApplier (rl/builders.py:241-352) -> network_loading x action_gap ->
+                     ObservationBuilder (rl/builders.py:25-238) + reward (rl/pz_pednet_env.py:548-581)
+  PedNetParallelEnv  single-env facade with the reference's dict-of-agents reset()/step() signature
+                   (rl/pz_pednet_env.py:143-254); it does not import pettingzoo/gymnasium.
+
+Layout of one action row: agents in the reference's order (separators first, rl/discovery.py:121-123), one width per
+separator, one width per controlled outgoing link of a gater.  Observation row: 4 features per separator,
+features_per_link x outdegree per gater (no padding).  ``reward_mode="reference"`` reproduces what the reference
+actually computes -- its ``return rewards`` sits inside the agent loop (pz_pednet_env.py:581), so only the first agent
+is ever rewarded; ``reward_mode="all"`` rewards every gater.
+"""
+import numpy as np
+
+OBS_MODES = {"option1": 1, "option2": 2, "option3": 3, "option4": 4, "option5": 5}
+FEATURES_PER_LINK = {"option1": 3, "option2": 4, "option3": 5, "option4": 2, "option5": 7}
+
+
+class AgentManager:
+    """Maps the scenario's ``controllers`` section to agents (rl/discovery.py)."""
+
+    def __init__(self, network):
+        self.network = network
+        self.separator_agents, self.gater_agents, self.agent_to_type = {}, {}, {}
+        for pair in network.controller_links:
+            a, b = sorted(int(x) for x in pair.split("-"))
+            fwd, rev = network.links.get((a, b)), network.links.get((b, a))
+            if not fwd or not rev:
+                raise ValueError(f"Missing bidirectional links for separator {(a, b)}")
+            if not fwd.is_separator:
+                raise ValueError(f"Link {a}->{b} is not a Separator. Use Separator links for lane control.")
+            aid = f"sep_{a}_{b}"
+            self.separator_agents[aid] = {"forward": fwd, "reverse": rev, "total_width": fwd._width}
+            self.agent_to_type[aid] = "sep"
+        for nid in network.controller_gaters:
+            if nid not in network.nodes:
+                raise ValueError(f"Gater node {nid} not found in network")
+            node = network.nodes[nid]
+            outs = [l for l in node.outgoing_links if not l.is_virtual and not l.is_separator]
+            if not outs:
+                raise ValueError(f"Gater node {nid} has no real outgoing links to control")
+            aid = f"gate_{nid}"
+            self.gater_agents[aid] = {"node": node, "out_links": outs}
+            self.agent_to_type[aid] = "gate"
+        self.max_outdegree = max((len(g["out_links"]) for g in self.gater_agents.values()), default=0)
+
+    def get_all_agent_ids(self):
+        return list(self.separator_agents.keys()) + list(self.gater_agents.keys())
+
+    def get_agent_type(self, agent_id):
+        if agent_id not in self.agent_to_type:
+            raise ValueError(f"Unknown agent ID: {agent_id}")
+        return self.agent_to_type[agent_id]
+
+    def get_separator_links(self, agent_id):
+        d = self.separator_agents[agent_id]
+        return d["forward"], d["reverse"]
+
+    def get_gater_node(self, agent_id):
+        return self.gater_agents[agent_id]["node"]
+
+    def get_gater_outgoing_links(self, agent_id):
+        return self.gater_agents[agent_id]["out_links"]
+
+    def get_max_outdegree(self, agent_id):
+        return len(self.gater_agents[agent_id]["out_links"])
+
+    def get_gater_action_mask(self, agent_id):
+        mask = np.zeros(self.max_outdegree, dtype=np.float32)
+        mask[:len(self.gater_agents[agent_id]["out_links"])] = 1.0
+        return mask
+
+    def flat_spec(self):
+        """(agent ids, type[], link_ptr[], links[]) in the layout of ``pedn_rl_desc``."""
+        ids = self.get_all_agent_ids()
+        types, ptr, links = [], [0], []
+        for aid in ids:
+            if self.agent_to_type[aid] == "sep":
+                f, r = self.get_separator_links(aid)
+                types.append(0)
+                links += [f.index, r.index]
+            else:
+                types.append(1)
+                links += [l.index for l in self.get_gater_outgoing_links(aid)]
+            ptr.append(len(links))
+        return ids, np.array(types, np.int32), np.array(ptr, np.int32), np.array(links, np.int32)
+
+
+class VecPedNetEnv:
+    """``n_envs`` replicas of one scenario stepped together on one GPU."""
+
+    def __init__(self, dataset, n_envs=1, obs_mode="option1", normalize_obs=False, action_gap=1, seed=0,
+                 reward_mode="reference", data_dir="data", replica_offset=0, device=0, network=None, verbose=False):
+        from .env_loader import NetworkEnvGenerator
+
+        if obs_mode not in OBS_MODES:
+            raise ValueError(f"obs_mode must be one of {list(OBS_MODES)}, got: {obs_mode}")
+        self.dataset, self.n_envs, self.obs_mode, self.normalize_obs = dataset, int(n_envs), obs_mode, bool(normalize_obs)
+        self.action_gap = int(action_gap)
+        self.env_generator = NetworkEnvGenerator(data_dir)
+        self.network = network or self.env_generator.create_network(dataset, verbose=verbose, n_replicas=self.n_envs,
+                                                                    rng_seed=seed, replica_offset=replica_offset, device=device)
+        self.simulation_steps = self.network.params["simulation_steps"]
+        ut = self.network.params["unit_time"]
+        self._max_delta_sep_width = 0.25 * ut          # pz_pednet_env.py:84-86
+        self._max_delta_gate_width = 0.25 * ut
+        self._min_sep_width = 1.5
+        self.agent_manager = AgentManager(self.network)
+        self.possible_agents, types, ptr, links = self.agent_manager.flat_spec()
+        if not self.possible_agents:
+            raise ValueError("scenario defines no controller agents")
+        self.features_per_link = FEATURES_PER_LINK[obs_mode]
+        eng = self.network.engine()
+        self.n_actions, self.n_obs = eng.rl_configure(types, ptr, links, OBS_MODES[obs_mode], normalize_obs,
+                                                      {"reference": 0, "all": 1}[reward_mode], self._max_delta_sep_width,
+                                                      self._max_delta_gate_width, self._min_sep_width)
+        self._types, self._ptr = types, ptr
+        # per-agent slices of the flat rows and action bounds (rl/spaces.py:41-73)
+        self.action_slices, self.obs_slices, lo, hi = {}, {}, [], []
+        a0 = o0 = 0
+        for aid, ty, p0, p1 in zip(self.possible_agents, types, ptr[:-1], ptr[1:]):
+            if ty == 0:
+                w = self.agent_manager.separator_agents[aid]["total_width"]
+                na, no = 1, 4
+                lo.append(self._min_sep_width)
+                hi.append(w - self._min_sep_width)
+            else:
+                outs = self.agent_manager.get_gater_outgoing_links(aid)
+                na, no = len(outs), len(outs) * self.features_per_link
+                lo += [0.0] * na
+                hi += [l.width for l in outs]
+            self.action_slices[aid] = slice(a0, a0 + na)
+            self.obs_slices[aid] = slice(o0, o0 + no)
+            a0 += na
+            o0 += no
+        self.action_low, self.action_high = np.array(lo, np.float32), np.array(hi, np.float32)
+        self.sim_step = 1
+
+    # ------------------------------------------------------------------------------------------------ API
+    def reset(self):
+        """All replicas back to t = 0 (state only: widths return to their initial values, demand and scenario are kept)."""
+        net = self.network
+        eng = net.engine()
+        eng.reset()
+        net._init_dynamic_host_state()
+        for which, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3)):
+            eng.set_widths(code, net._widths[which])
+        net.current_step = 0
+        self.sim_step = 1
+        obs, _ = eng.rl_observe(self.sim_step, accumulate=False)
+        return obs, {}
+
+    def step(self, actions, fetch=True):
+        """actions [n_envs, n_actions] widths in metres (None = keep the current widths)."""
+        if self.sim_step + self.action_gap - 1 > self.simulation_steps:
+            raise IndexError("episode is over; call reset()")
+        eng = self.network._flush()
+        obs, rew = eng.rl_step(actions, self.sim_step, self.action_gap, fetch=fetch)
+        self.sim_step += self.action_gap
+        self.network.current_step = self.sim_step - 1
+        self.network._widths_stale = True
+        terminated = (self.sim_step - 1) >= self.simulation_steps     # pz_pednet_env.py:592 evaluated before the increment
+        return obs, rew, terminated, False, {}
+
+    def split_obs(self, obs_row):
+        return {aid: obs_row[..., sl] for aid, sl in self.obs_slices.items()}
+
+    def close(self):
+        self.network.close()
+
+
+class PedNetParallelEnv:
+    """Single-env facade with the reference's dict-of-agents interface (rl/pz_pednet_env.py:37-254)."""
+
+    metadata = {"render_modes": [], "name": "pednet_v0"}
+
+    def __init__(self, dataset, normalize_obs=False, obs_mode="option1", render_mode=None, verbose=False, action_gap=1,
+                 seed=None, **kw):
+        self._vec = VecPedNetEnv(dataset, n_envs=1, obs_mode=obs_mode, normalize_obs=normalize_obs, action_gap=action_gap,
+                                 seed=0 if seed is None else seed, verbose=verbose, **kw)
+        self.network = self._vec.network
+        self.agent_manager = self._vec.agent_manager
+        self.possible_agents = list(self._vec.possible_agents)
+        self.simulation_steps = self._vec.simulation_steps
+        self._cumulative_rewards = {a: 0.0 for a in self.possible_agents}
+
+    @property
+    def agents(self):
+        return self.possible_agents.copy()
+
+    @property
+    def sim_step(self):
+        return self._vec.sim_step
+
+    def _dict(self, row):
+        return {a: np.array(row[sl]) for a, sl in self._vec.obs_slices.items()}
+
+    def reset(self, seed=None, options=None):
+        obs, _ = self._vec.reset()
+        self._cumulative_rewards = {a: 0.0 for a in self.possible_agents}
+        return self._dict(obs[0]), {a: {} for a in self.possible_agents}
+
+    def step(self, actions):
+        for a in actions:
+            if a not in self.possible_agents:
+                raise ValueError(f"Unknown agent: {a}")
+        row = None
+        if len(actions) > 0:
+            # agents without an action keep their current widths (apply_all_actions only touches the given agents)
+            row = np.empty((1, self._vec.n_actions))
+            net = self.network
+            for aid, sl in self._vec.action_slices.items():
+                if aid in actions:
+                    row[0, sl] = np.asarray(actions[aid], dtype=np.float64).reshape(-1)
+                elif self.agent_manager.get_agent_type(aid) == "sep":
+                    row[0, sl] = self.agent_manager.get_separator_links(aid)[0].separator_width
+                else:
+                    row[0, sl] = [l.back_gate_width for l in self.agent_manager.get_gater_outgoing_links(aid)]
+        obs, rew, term, trunc, _ = self._vec.step(row)
+        rewards = {a: float(rew[0, i]) for i, a in enumerate(self.possible_agents)}
+        for a, r in rewards.items():
+            self._cumulative_rewards[a] += r
+        return (self._dict(obs[0]), rewards, {a: term for a in self.possible_agents},
+                {a: False for a in self.possible_agents}, {a: {} for a in self.possible_agents})
+
+    def close(self):
+        self._vec.close()

@@ -87,7 +87,7 @@ def run_oracle(g: Golden, net=None, steps=None):
         for mut in g.mutations:
             if mut[0] == t:
                 apply_mutation(net, mut)
-                for which, code in (("front", 0), ("back", 1), ("sep", 2)):
+                for which, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3)):
                     for l in range(model["n_links"]):
                         o.set_width(code, l, net._widths[which][l, 0])
     return o, np.array(tfh), model, net

@@ -1,0 +1,93 @@
+"""GPU tests of the batched RL step (config #5 caller): device action clipping / observation / reward kernels against the
+goldens captured from the reference's rl modules and against the CPU restatement for many envs."""
+import numpy as np
+import pytest
+
+from golden_util import Golden, build_network, compare_fields
+from pednstream_amd.flatten import flatten_network
+from pednstream_amd.network import LINK_FIELDS
+from pednstream_amd.rl_env import PedNetParallelEnv, VecPedNetEnv
+from rl_oracle import RlOracle
+from test_rl_golden import RL_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", RL_CASES)
+def test_vec_env_reproduces_reference_rl_goldens(case):
+    g = Golden(case)
+    rl = g.info["rl"]
+    net = build_network(g, n_replicas=1, replica_offset=g.replica, rng_seed=g.seed)
+    env = VecPedNetEnv(g.info["scenario"], n_envs=1, obs_mode=rl["obs_mode"], normalize_obs=rl["normalize"],
+                       action_gap=rl["action_gap"], network=net)
+    assert env.possible_agents == [a["id"] for a in rl["agents"]]
+    acts, ref_obs, ref_rew = g.state("rl_actions"), g.state("rl_obs"), g.state("rl_rewards")
+    assert (env.n_actions, env.n_obs) == (acts.shape[1], ref_obs.shape[1])
+    for k in range(rl["env_steps"]):
+        obs, rew, term, trunc, _ = env.step(acts[k:k + 1])
+        assert np.array_equal(obs[0], ref_obs[k]), (k, obs[0], ref_obs[k])
+        assert np.array_equal(rew[0], ref_rew[k]), (k, rew[0], ref_rew[k])
+        assert term is False
+    e = net._engine
+    problems = compare_fields(lambda name: e.read_block(LINK_FIELDS[name][0], 0, g.steps)[:, :, 0].T, g, e.n_links, g.steps)
+    assert not problems, "\n".join(problems)
+    # the host mirror of the widths follows the device-side actions
+    first = rl["agents"][0]
+    u, v = (int(x) for x in first["links"][0].split("_"))
+    w = net.links[(u, v)].separator_width if first["type"] == "sep" else net.links[(u, v)].back_gate_width
+    assert 0.0 <= w <= net.links[(u, v)].width
+    env.close()
+
+
+def test_many_envs_match_cpu_restatement():
+    g = Golden("rl_nine_opt3")
+    B, steps = 64, 50
+    net = build_network(g, n_replicas=B, rng_seed=4)
+    env = VecPedNetEnv("nine_intersections", n_envs=B, obs_mode="option5", action_gap=2, network=net, reward_mode="all")
+    rng = np.random.default_rng(9)
+    actions = rng.uniform(-0.5, 4.5, size=(steps, B, env.n_actions)).astype(np.float32)
+    model = flatten_network(net)
+    checks = {r: RlOracle(net, model, g.info["rl"]["agents"], "option5", False, 2, seed=4, replica=r, reward_mode="all") for r in (0, 17, 63)}
+    for k in range(steps):
+        obs, rew, *_ = env.step(actions[k])
+        for r, orc in checks.items():
+            o, w = orc.step(actions[k, r])
+            assert np.array_equal(obs[r], o), (k, r)
+            assert np.array_equal(rew[r], w), (k, r)
+    assert (rew[:, 1:] != 0).any()          # reward_mode="all": agents after the first are rewarded too
+    env.close()
+
+
+def test_single_env_facade_and_reset():
+    g = Golden("rl_nine_opt3")
+    env = PedNetParallelEnv("nine_intersections", obs_mode="option3", seed=g.seed, network=build_network(g, n_replicas=1, replica_offset=g.replica, rng_seed=g.seed))
+    acts, ref_obs, ref_rew = g.state("rl_actions"), g.state("rl_obs"), g.state("rl_rewards")
+
+    def run(n):
+        out = []
+        for k in range(n):
+            actions = {a: acts[k, sl] for a, sl in env._vec.action_slices.items()}
+            obs, rew, term, trunc, info = env.step(actions)
+            flat = np.concatenate([obs[a] for a in env.possible_agents])
+            assert np.array_equal(flat, ref_obs[k]) and np.array_equal(np.float32([rew[a] for a in env.possible_agents]), ref_rew[k])
+            assert set(obs) == set(env.possible_agents) and not any(term.values())
+            out.append(flat)
+        return out
+
+    obs0, _ = env.reset()
+    assert all((v == np.float32([0, 0, 0, 0, 4] * (len(v) // 5))).all() for v in obs0.values())   # initial obs [0,0,0,0,width]
+    first = run(30)
+    env.reset()
+    second = run(30)                                  # reset restores state and widths: identical replay
+    assert all(np.array_equal(a, b) for a, b in zip(first, second))
+    with pytest.raises(ValueError):
+        env.step({"gate_99": np.zeros(3)})
+    env.close()
+
+
+def test_reference_index_errors_are_reported():
+    g = Golden("rl_nine_opt4")
+    with pytest.raises(IndexError):
+        VecPedNetEnv("nine_intersections", n_envs=1, obs_mode="option4", normalize_obs=True, network=build_network(g))
+    with pytest.raises(ValueError):
+        VecPedNetEnv("nine_intersections", n_envs=1, obs_mode="option9", network=build_network(g))
