@@ -84,6 +84,47 @@ def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024):
     return (k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
 
 
+def bench_rl(args):
+    """BASELINE config #5: env-steps/s of the batched RL step (action clipping + network_loading + observations + rewards)
+    on 45_intersections x 2048 envs, obs option3, action_gap 1, uniform random actions resident in HBM."""
+    import torch
+
+    from pednstream_amd.rl_env import VecPedNetEnv
+
+    B = args.replicas
+    env = VecPedNetEnv(args.network, n_envs=B, obs_mode="option3", action_gap=1, seed=0, data_dir=os.path.join(ROOT, "data"))
+    e = env.network.engine()
+    T = env.simulation_steps
+    K = min(args.steps, T - 1 - args.warmup)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    hi = torch.as_tensor(env.action_high, device="cuda", dtype=torch.float64)
+    acts = torch.rand((args.warmup + K, B, env.n_actions), generator=gen, device="cuda", dtype=torch.float64) * hi
+    torch.cuda.synchronize()
+    row = B * env.n_actions * 8
+    t = 1
+    for k in range(args.warmup):
+        e.rl_step_device(acts.data_ptr() + k * row, t)
+        t += 1
+    e.synchronize()
+    e.timer_begin()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + K):
+        e.rl_step_device(acts.data_ptr() + k * row, t)
+        t += 1
+    dev_ms = e.timer_end()
+    wall = time.perf_counter() - t0
+    rc, _ = e.error_flags()
+    assert rc == 0
+    out = {"metric": "env-steps/sec (replicas x steps/sec, incl. action apply, observations, rewards)", "value": B * K / wall,
+           "unit": "env-steps/s", "n_gpus": 1, "steps": K, "warmup": args.warmup, "ms_per_step": wall / K * 1e3,
+           "device_ms_per_step": dev_ms / K, "higher_is_better": True, "data": "synthetic", "dtype": "f64+f32",
+           "link_updates_per_s": e.n_links * B * K / wall,
+           "config": {"workload": f"{args.network} x {B} envs, obs option3 ({env.n_obs} floats), {env.n_actions} action dims, "
+                                  f"agents {env.possible_agents}, actions resident in HBM (torch), obs/rewards left on device"}}
+    print(json.dumps(out), flush=True)
+    env.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +136,10 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--rl", action="store_true", help="config #5 instead: batched RL env step, env-steps/s")
     args = ap.parse_args()
+    if args.rl:
+        return bench_rl(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -306,6 +306,11 @@ class Engine:
                                         None if rew is None else rew.ctypes.data_as(C.c_void_p)))
         return obs, rew
 
+    def rl_step_device(self, actions_ptr, t, action_gap=1):
+        """Same as rl_step with the action rows already resident in HBM (raw device pointer, e.g. torch ``data_ptr()``);
+        observations and rewards stay in the device buffers (``rl_device_ptr``)."""
+        self._ck(self._lib.pedn_rl_step(self._h, C.c_void_p(int(actions_ptr)), 1, int(t), int(action_gap), None, None))
+
     def rl_device_ptr(self, which):
         return self._lib.pedn_rl_device_ptr(self._h, int(which))
 
