@@ -20,7 +20,7 @@ int main(void) {
     printf("powf(x, %g): %ld mismatches over %u inputs\n", (double)y, bad, 0x3f800001u);
   }
   long bad = 0, n = 0; double maxulp = 0;
-  for (double x = -60.0; x < 5.0; x += 1.234567e-5) {
+  for (double x = -300.0; x < 300.0; x += 1.234567e-5) {
     double a = pedn_oracle_exp(x), b = exp(x);
     ++n;
     if (a != b) { ++bad; double u = fabs(a - b) / (nextafter(b, INFINITY) - b); if (u > maxulp) maxulp = u; }

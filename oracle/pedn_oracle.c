@@ -156,48 +156,40 @@ float pw_powf(float x, float y) {
   return (float)e;
 }
 
-/* exp(x) for the softmax.  Argument reduction x = k*ln2/64 + r with a 64-entry table of 2^(j/64) split hi+lo
- * (computed below from exact dyadic arithmetic at start-up would need long double; instead the table is generated
- * by repeated correctly-rounded operations that are identical on every IEEE-754 machine) and a degree-6 Taylor
- * polynomial.  Error < 1 ulp; identical on CPU and GPU because only +,*,- on binary64 are used. */
-static double PW_EXPTAB_HI[64], PW_EXPTAB_LO[64];
-static int pw_exp_ready = 0;
-static const uint64_t PW_EXPTAB_BITS[64][2] = {
+/* exp(x) for the softmax (path_finder.py:585): numpy's double exp loop falls through to libm's exp (with the AVX512F
+ * loop disabled, see oracle/ref_harness.py), i.e. glibc 2.35 `__exp_fma` on every x86 with FMA (sysdeps/ieee754/dbl-64/e_exp.c
+ * built with -mfma -mavx2, selected by ifunc).  The algorithm (N = 128 table of 2^(k/128), degree-5 polynomial) is
+ * restated here with the SAME fused multiply-adds the shipped binary uses (read off its disassembly):
+ *   kd+Shift = fma(x, InvLn2N, Shift);  r = fma(kd, NegLn2loN, fma(kd, NegLn2hiN, x));
+ *   tmp = fma(r2*r2, fma(r, C5, C4), fma(fma(r, C3, C2), r2, tail + r));  result = fma(scale, tmp, scale)
+ * fma() is exact by definition, so CPU and GPU agree bit for bit.  Domain of the main path: 2^-54 <= |x| < 512. */
+static const uint64_t PW_EXP_TAB[128][2] = {
 #include "exp_table.inc"
 };
-static void pw_exp_init(void) {
-  for (int j = 0; j < 64; ++j) {
-    PW_EXPTAB_HI[j] = u2d(PW_EXPTAB_BITS[j][0]);
-    PW_EXPTAB_LO[j] = u2d(PW_EXPTAB_BITS[j][1]);
-  }
-  pw_exp_ready = 1;
-}
 
 double pw_exp(double x) {
-  if (!pw_exp_ready) pw_exp_init();
-  if (x != x) return x;
-  if (x > 709.0) return INFINITY;
-  if (x < -745.0) return 0.0;
-  const double INV_LN2_64 = 0x1.71547652b82fep+6;     /* 64/ln2 */
-  const double LN2_64_HI = 0x1.62e42fefa0000p-7;      /* ln2/64, 32 trailing zero bits */
-  const double LN2_64_LO = 0x1.cf79abc9e3b3ap-46;
-  double kd = floor(x * INV_LN2_64 + 0.5);
-  int64_t k = (int64_t)kd;
-  double r = (x - kd * LN2_64_HI) - kd * LN2_64_LO;
-  int j = (int)(k & 63);
-  int64_t e = (k - j) / 64;
-  double r2 = r * r;
-  /* exp(r) - 1 = r + r^2/2 + r^3/6 + r^4/24 + r^5/120 + r^6/720, |r| <= ln2/128 */
-  double p = r + r2 * (0.5 + r * (0x1.5555555555555p-3 + r * (0x1.5555555555555p-5 + r * (0x1.1111111111111p-7 + r * 0x1.6c16c16c16c17p-10))));
-  double hi = PW_EXPTAB_HI[j], lo = PW_EXPTAB_LO[j];
-  double v = hi + (lo + (hi + lo) * p);
-  /* scale by 2^e without ldexp rounding surprises: e within [-1100, 1100], split */
-  if (e > -1000 && e < 1000) {
-    return v * u2d((uint64_t)(e + 1023) << 52);
+  uint32_t abstop = (uint32_t)(d2u(x) >> 52) & 0x7ff;
+  if (abstop - 0x3c9u >= 0x3fu) {
+    if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x; /* |x| < 2^-54 */
+    if (x != x) return x;
+    if (abstop >= 0x409u) return (d2u(x) >> 63) ? 0.0 : INFINITY; /* |x| >= 1024 */
+    /* 512 <= |x| < 1024: outside the softmax's range; libm's special-case scaling is not restated */
+    return exp(x);
   }
-  double h = u2d((uint64_t)(e / 2 + 1023) << 52);
-  double g = u2d((uint64_t)(e - e / 2 + 1023) << 52);
-  return v * h * g;
+  const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+  double kd = fma(x, InvLn2N, Shift);
+  uint64_t ki = d2u(kd);
+  kd -= Shift;
+  double r = fma(kd, NegLn2loN, fma(kd, NegLn2hiN, x));
+  uint64_t idx = ki % 128;
+  uint64_t top = ki << 45;
+  double tail = u2d(PW_EXP_TAB[idx][0]);
+  uint64_t sbits = PW_EXP_TAB[idx][1] + top;
+  double r2 = r * r;
+  double tmp = fma(r2 * r2, fma(r, C5, C4), fma(fma(r, C3, C2), r2, tail + r));
+  double scale = u2d(sbits);
+  return fma(scale, tmp, scale);
 }
 
 /* ------------------------------------------------------------------------------------------------ state */

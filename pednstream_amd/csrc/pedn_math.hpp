@@ -2,7 +2,7 @@
 //
 // Everything here must be bit-identical to what the reference computes on the host through numpy/libm:
 //   * pedn_powf   : glibc 2.35 powf algorithm (numpy float32 scalar power == libm powf; link.py:212,317)
-//   * pedn_exp    : table + Taylor exp, < 1 ulp (softmax, path_finder.py:585)
+//   * pedn_exp    : glibc 2.35 exp (FMA build) restated (softmax, path_finder.py:585)
 //   * Philox4x32-10 keyed (seed, replica, link, t, site) -> binomial / normal  (RNG contract)
 // Only IEEE-754 +,-,*,/,sqrt,floor on binary32/binary64 are used; the translation unit is compiled with
 // -ffp-contract=off so that no multiply-add is fused.
@@ -79,30 +79,33 @@ __device__ inline float pedn_powf(float x, float y) {
 }
 
 // ---- exp ------------------------------------------------------------------------------------------------------
-__device__ const uint64_t kExpTab[64][2] = {
+// glibc 2.35 __exp_fma restated (N = 128 table, degree-5 polynomial, the shipped binary's fused multiply-adds); see
+// oracle/pedn_oracle.c pw_exp for the derivation.  Main path 2^-54 <= |x| < 512; the softmax never leaves it.
+__device__ const uint64_t kExpTab[128][2] = {
 #include "exp_table.inc"
 };
 
 __device__ inline double pedn_exp(double x) {
-  if (x != x) return x;
-  if (x > 709.0) return __longlong_as_double(0x7ff0000000000000ll);
-  if (x < -745.0) return 0.0;
-  const double INV_LN2_64 = 0x1.71547652b82fep+6;
-  const double LN2_64_HI = 0x1.62e42fefa0000p-7;
-  const double LN2_64_LO = 0x1.cf79abc9e3b3ap-46;
-  double kd = floor(x * INV_LN2_64 + 0.5);
-  long long k = (long long)kd;
-  double r = (x - kd * LN2_64_HI) - kd * LN2_64_LO;
-  int j = (int)(k & 63);
-  long long e = (k - j) / 64;
+  uint32_t abstop = (uint32_t)(d2u(x) >> 52) & 0x7ffu;
+  if (abstop - 0x3c9u >= 0x3fu) {
+    if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;
+    if (x != x) return x;
+    if (abstop >= 0x409u) return (d2u(x) >> 63) ? 0.0 : __longlong_as_double(0x7ff0000000000000ll);
+    return exp(x);  // 512 <= |x| < 1024: not reachable from the softmax, not bit-pinned
+  }
+  const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
+  const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
+  double kd = fma(x, InvLn2N, Shift);
+  uint64_t ki = d2u(kd);
+  kd -= Shift;
+  double r = fma(kd, NegLn2loN, fma(kd, NegLn2hiN, x));
+  uint64_t idx = ki & 127u;
+  double tail = u2d(kExpTab[idx][0]);
+  uint64_t sbits = kExpTab[idx][1] + (ki << 45);
   double r2 = r * r;
-  double p = r + r2 * (0.5 + r * (0x1.5555555555555p-3 + r * (0x1.5555555555555p-5 + r * (0x1.1111111111111p-7 + r * 0x1.6c16c16c16c17p-10))));
-  double hi = u2d(kExpTab[j][0]), lo = u2d(kExpTab[j][1]);
-  double v = hi + (lo + (hi + lo) * p);
-  if (e > -1000 && e < 1000) return v * u2d((uint64_t)(e + 1023) << 52);
-  double h = u2d((uint64_t)(e / 2 + 1023) << 52);
-  double g = u2d((uint64_t)(e - e / 2 + 1023) << 52);
-  return v * h * g;
+  double tmp = fma(r2 * r2, fma(r, C5, C4), fma(fma(r, C3, C2), r2, tail + r));
+  double scale = u2d(sbits);
+  return fma(scale, tmp, scale);
 }
 
 // ---- RNG contract -----------------------------------------------------------------------------------------------

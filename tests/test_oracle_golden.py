@@ -24,8 +24,7 @@ def test_oracle_reproduces_reference_bit_exact(case):
             for name in ("inflow", "outflow", "cumulative_inflow", "cumulative_outflow"):
                 mine = o.field(name)[L + off::2, :g.steps]
                 assert np.array_equal(mine, g.state(f"{tag}_{name}")[:, :g.steps]), (tag, name)
-    # turning fractions: the softmax uses exp(); the reference's exp is libm's (FMA build), ours is an independent
-    # < 1 ulp implementation, so fractions may differ in the last bits -- never more.
+    # turning fractions: the softmax's exp() is glibc 2.35's, restated with its fused multiply-adds -> bit-exact too
     ref_tf = g.z["tf_hist"]
     assert tfh.shape == ref_tf.shape
-    assert np.max(np.abs(tfh - ref_tf), initial=0.0) <= 4.5e-16
+    assert np.array_equal(tfh, ref_tf)

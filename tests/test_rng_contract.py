@@ -61,10 +61,22 @@ def test_powf_restatement_matches_numpy_float32_scalar_power():
             assert np.float32(L.pedn_oracle_powf(float(x), float(np.float32(y)))) == x ** y
 
 
-def test_exp_is_within_one_ulp_of_numpy():
+def test_exp_restatement_matches_libm_exp():
+    """np.exp on a double array reaches libm's exp when numpy's AVX512F loop is disabled (oracle/ref_harness.py); the
+    oracle restates glibc 2.35's FMA build of it and must agree bit for bit on this machine's libm."""
+    import ctypes
+    import ctypes.util
+
     L = od.lib()
-    xs = np.linspace(-40, 3, 20001)
-    mine = np.array([L.pedn_oracle_exp(float(x)) for x in xs])
-    ref = np.exp(xs)
-    assert np.all(np.abs(mine - ref) <= np.spacing(ref))
+    libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    libm.exp.restype = ctypes.c_double
+    libm.exp.argtypes = [ctypes.c_double]
+    rng = np.random.default_rng(2)
+    xs = np.concatenate([np.linspace(-40, 3, 20001), -rng.random(20000) * 100, [0.0, -0.0, 1e-300, -1e-20, 1.0, -1.0]])
+    mism = sum(1 for x in xs if L.pedn_oracle_exp(float(x)) != libm.exp(float(x)))
+    import platform
+    if platform.libc_ver()[1] == "2.35":
+        assert mism == 0
+    else:       # another glibc may round a few arguments differently; the restatement itself is < 1 ulp
+        assert all(abs(L.pedn_oracle_exp(float(x)) - np.exp(x)) <= np.spacing(np.exp(x)) for x in xs[::50])
     assert L.pedn_oracle_exp(0.0) == 1.0
