@@ -150,6 +150,27 @@ def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_s
     save(case, static, state, extras, info)
 
 
+def output_case(case, name, mutations=None, np_seed=20261003):
+    """what the reference's own OutputHandler.save_network_state writes for a run (the JSON texts are
+    stored zlib-compressed; inputs as in scenario_case)."""
+    import tempfile
+    import zlib
+
+    net = scenario_case(case, name, mutations=mutations, np_seed=np_seed)
+    sys.path.insert(0, rh.REF_ROOT)
+    from handlers.output_handler import OutputHandler
+
+    with tempfile.TemporaryDirectory() as tmp:
+        OutputHandler(base_dir=tmp, simulation_dir="run").save_network_state(net)
+        texts = {f: open(os.path.join(tmp, "run", f + ".json"), "rb").read() for f in ("link_data", "node_data", "network_params")}
+    path = os.path.join(OUT, case + ".npz")
+    z = dict(np.load(path))
+    for k, v in texts.items():
+        z["json_" + k] = np.frombuffer(zlib.compress(v, 9), dtype=np.uint8)
+    np.savez_compressed(path, **z)
+    print(f"{case}: + reference OutputHandler JSON ({sum(len(v) for v in texts.values()) / 1024:.0f} KiB raw), {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def kat_native():
     """G1 / G1b: the reference under its own numpy RNG (yaml seed 42 reseeds the global stream)."""
     ref = rh.load_reference()
@@ -251,6 +272,9 @@ CASES = {
                                                      (200, "back_gate_set", 3, 4, 1.1)]),
 }
 CASES.update({
+    "output_six_node": lambda: output_case("output_six_node", "od_flow_example",
+                                           mutations=[(t, "back_gate_delta", 3, 5, -0.1) for t in range(100, 109)]),
+    "output_corridor": lambda: output_case("output_corridor", "long_corridor", mutations=[(150, "separator_set", 2, 3, 1.25)]),
     "rl_nine_opt3": lambda: rl_case("rl_nine_opt3", "nine_intersections", obs_mode="option3", env_steps=200),
     "rl_nine_opt2n": lambda: rl_case("rl_nine_opt2n", "nine_intersections", obs_mode="option2", normalize=True, env_steps=120, action_seed=2),
     "rl_nine_opt5g2": lambda: rl_case("rl_nine_opt5g2", "nine_intersections", obs_mode="option5", action_gap=2, env_steps=90, action_seed=3),
