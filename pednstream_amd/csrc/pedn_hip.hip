@@ -43,6 +43,16 @@ struct LinkP {  // static per-link parameters, wave-uniform on the device
   int32_t pad[2];
 };
 
+struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything static it needs, fetched by ONE scalar load burst
+  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, pad0, pad1;
+  LinkP Pin, Pout;  // parameters of the incoming / outgoing link of the slot (unused for a virtual pair)
+};
+
+struct CorrRec {  // one lane group of link_kernel: both directions of a corridor
+  int32_t a, b, pad0, pad1;
+  LinkP Pa, Pb;
+};
+
 struct EntS {  // one downstream entry of a softmax group (update_node_turn_probs, path_finder.py:561-589)
   int32_t link, rev, sep;  // outgoing link (-1: virtual), its reverse, separator flag
   float area32;            // float32(length * width) of a plain link
@@ -55,10 +65,15 @@ struct DevView {
   float* f32[6];
   float* rsum;
   double *front, *back, *sepw, *sepnp, *tf, *demand, *ent_p;
+  // replica-uniform shortcuts (NaN = the value differs between replicas, read the per-replica row instead): a value every
+  // replica shares is one scalar load per wave instead of 8 bytes per lane
+  const double *front_u, *back_u;  // [L]
+  const double* tf_u;              // [n_turns]
   const double* od_w;
   uint32_t* flags;
   const LinkP* lp;
-  const int4* wave_desc;
+  const SlotRec* slot_rec;
+  const CorrRec* corr_rec;
   const int32_t *node_kind, *node_slot_ptr, *node_turn_ptr, *node_demand_row, *node_dyn, *slot_in, *slot_out;
   const int32_t *grp_ent_ptr, *grp_allphys, *ent_pair, *turn_pair_ptr;
   const struct EntS* ents;      // static per-entry data of the softmax groups
@@ -67,7 +82,6 @@ struct DevView {
   const int32_t* turn_mode;     // [n_turns] 1: every product of the turn is constant -> fraction tabulated per step on the host
   const double* turn_tab;       // [T+1][n_turns] tabulated raw fractions of such turns
   const double* pair_pod;  // [T+1][n_pair] P(od | up) of the pair's upstream group, replica independent
-  const int32_t* pair_a;  // corridor list for link_kernel
   int32_t L, Lall, T1, RS, R, W, n_grp, n_multi, n_pairs_corr, n_pair, n_turns;
   double dt, pf_temp, pf_alpha, pf_beta, pf_omega, pf_eps;
   uint32_t k0, k1, replica_offset;
@@ -91,27 +105,31 @@ __device__ __forceinline__ float dens_at(const DevView& v, const LinkP& P, int l
   return n / (float)(P.length * P.width);
 }
 
-// Link.cal_sending_flow (link.py:216-370) incl. get_outflow (:199-214); nself/nrev = num_pedestrians[t'] of l / reverse
-__device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, float nself, float nrev, uint32_t& fl) {
-  const int L = v.L, RS = v.RS, T1 = v.T1;
-  double* S = v.f64[F_S];
-  if (tp < P.fft) {  // link.py:267-269
-    S[at(tp, l, L, RS, r)] = 0.0;
-    return 0.0;
-  }
-  float kk = v.f32[G_K][at(tp, l, L, RS, r)];
-  float att = v.f32[G_ATT][at(tp, l, L, RS, r)];
-  double aw = P.sep ? v.sepw[(size_t)l * RS + r] : P.width;
+// Everything of step t' = t-1 a slot wave needs from HBM whose address does not depend on data: fetched as ONE batch of
+// independent loads at the top of node_kernel (the wave then waits once instead of once per dependent use; the kernel is
+// latency-bound: 76 % of its wave-cycles were s_waitcnt with the loads left where the formulas use them).
+struct SlotIn {
+  float n_in, n_out, k_in, att_in;        // num_pedestrians[t'] of the incoming / outgoing link, density and avg travel time
+  double co_in, s_prev, front_in, sepw_in;   // incoming link: cumulative_outflow[t'], sending_flow[t'-1], front gate, separator width
+  double co_sw, ci_out, r_prev, back_out, sepw_out;  // outgoing link: cumulative_outflow[t'+1-tau_sw], cumulative_inflow[t'],
+                                                     // receiving_flow[t'-1], back gate, separator width
+};
+
+// Link.cal_sending_flow (link.py:216-370) incl. get_outflow (:199-214) for t' >= free_flow_tau
+__device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, uint32_t& fl) {
+  const int RS = v.RS, T1 = v.T1;
+  const float nself = x.n_in, nrev = x.n_out, kk = x.k_in, att = x.att_in;
+  double aw = P.sep ? x.sepw_in : P.width;
   float dens = P.sep ? kk : (nself + nrev) / (float)(P.length * aw);
   int tau = __float2int_rn(att / (float)v.dt);  // link.py:260
   if (tau <= 0) fl |= PEDN_F_SAME_STEP;
   int idx = tp + 1 - tau;
   if (idx < 0) idx = 0;
   float cf = clip01((kk - (float)P.kc) / (float)(P.kj - P.kc));  // link.py:282
-  double ff = v.f64[F_CI][at(idx, l, v.Lall, RS, r)] - v.f64[F_CO][at(tp, l, v.Lall, RS, r)];
+  double ff = v.f64[F_CI][at(idx, l, v.Lall, RS, r)] - x.co_in;  // the one data-dependent look-back of the common path
   if (!(ff > 0.0)) ff = 0.0;
   double bnd = (double)(cf * nself) + (double)(1.0f - cf) * ff;  // link.py:284-288
-  double smax = v.front[(size_t)l * RS + r] * P.kc * P.vf * v.dt;  // link.py:296
+  double smax = x.front_in * P.kc * P.vf * v.dt;                 // link.py:296
   double s = smax < bnd ? smax : bnd;
   double orig = s;
   RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)tp, 0u};
@@ -123,10 +141,9 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
       float F = 1.0f / (1.0f + (float)P.gamma * att);
       float G = 1.0f - F;
       const double* in = v.f64[F_IN];
-      double d = (double)F * in[at(wrap_idx(tp - tau, T1, fl), l, v.Lall, RS, r)] +
-                 (double)(F * G) * in[at(wrap_idx(tp - tau - 1, T1, fl), l, v.Lall, RS, r)] +
-                 (double)(F * pedn_powf(G, 2.0f)) * in[at(wrap_idx(tp - tau - 2, T1, fl), l, v.Lall, RS, r)] +
-                 (double)(F * pedn_powf(G, 3.0f)) * in[at(wrap_idx(tp - tau - 3, T1, fl), l, v.Lall, RS, r)];
+      double i0 = in[at(wrap_idx(tp - tau, T1, fl), l, v.Lall, RS, r)], i1 = in[at(wrap_idx(tp - tau - 1, T1, fl), l, v.Lall, RS, r)];
+      double i2 = in[at(wrap_idx(tp - tau - 2, T1, fl), l, v.Lall, RS, r)], i3 = in[at(wrap_idx(tp - tau - 3, T1, fl), l, v.Lall, RS, r)];
+      double d = (double)F * i0 + (double)(F * G) * i1 + (double)(F * pedn_powf(G, 2.0f)) * i2 + (double)(F * pedn_powf(G, 3.0f)) * i3;
       d = ceil(d);
       if (d > 0.0) {  // link.py:326-330
         double mix = 0.8 * d + (1 - 0.8) * s;
@@ -145,17 +162,16 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
     s -= rng_binomial((long long)floor(s), P.act, key, v.meanfield);
   }
   if (!(s > 0.0)) s = 0.0;
-  double sm = floor(0.8 * s + 0.2 * S[at(wrap_idx(tp - 1, T1, fl), l, L, RS, r)]);  // link.py:364
+  double sm = floor(0.8 * s + 0.2 * x.s_prev);  // link.py:364
   s = orig < sm ? orig : sm;
   if (s < 0.0) fl |= PEDN_F_NEG_SENDING;
-  S[at(tp, l, L, RS, r)] = s;
   return s;
 }
 
-// Link/Separator.cal_receiving_flow[_with_reverse] (link.py:372-416,480-512); nrev = num_pedestrians[t'] of reverse
-__device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int r, float nrev, double s_rev, uint32_t& fl) {
-  const int L = v.L, RS = v.RS, T1 = v.T1;
-  double aw = P.sep ? v.sepw[(size_t)l * RS + r] : P.width;
+// Link/Separator.cal_receiving_flow[_with_reverse] (link.py:372-416,480-512); the reverse link is the slot's incoming link
+__device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, double s_rev, uint32_t& fl) {
+  const float nrev = x.n_in;
+  double aw = P.sep ? x.sepw_out : P.width;
   double kjA = P.kj * (P.length * aw);
   int tsw = P.tau_sw;
   double b;
@@ -163,7 +179,7 @@ __device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int
     if (tp + 1 - tsw < 0) b = kjA;
     else {
       if (tsw <= 0) fl |= PEDN_F_SAME_STEP;
-      b = v.f64[F_CO][at(tp + 1 - tsw, l, v.Lall, RS, r)] + kjA - v.f64[F_CI][at(tp, l, v.Lall, RS, r)];
+      b = x.co_sw + kjA - x.ci_out;
     }
   } else {
     if (nrev < 0.0f) fl |= PEDN_F_NEG_BINOM;
@@ -172,16 +188,15 @@ __device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int
     if (tp + 1 - tsw < 0) b = kjA - rp;
     else {
       if (tsw <= 0) fl |= PEDN_F_SAME_STEP;
-      b = v.f64[F_CO][at(tp + 1 - tsw, l, v.Lall, RS, r)] + kjA - rp - v.f64[F_CI][at(tp, l, v.Lall, RS, r)];
+      b = x.co_sw + kjA - rp - x.ci_out;
       if (!(b > 0.0)) b = 0.0;
     }
   }
-  double rmax = v.back[(size_t)l * RS + r] * P.kc * P.vf * v.dt;  // link.py:393
+  double rmax = x.back_out * P.kc * P.vf * v.dt;  // link.py:393
   double rr = rmax < b ? rmax : b;
   if (!(rr > 0.0)) rr = 0.0;
-  double prev = v.f64[F_R][at(wrap_idx(tp - 1, T1, fl), l, L, RS, r)];
-  if (prev >= 0.0) {  // link.py:400-401
-    double sm = floor(rr * 0.8 + prev * 0.2);
+  if (x.r_prev >= 0.0) {  // link.py:400-401
+    double sm = floor(rr * 0.8 + x.r_prev * 0.2);
     rr = sm < rr ? sm : rr;
   }
   if (P.sep) return rr > 0.0 ? rr : 0.0;
@@ -262,41 +277,73 @@ __global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   const int r = (int)blockIdx.y * 64 + lane;
   const int tp = t - 1;
-  const int4 wd = v.wave_desc[(size_t)blockIdx.x * 8 + wave];
-  const int node = __builtin_amdgcn_readfirstlane(wd.x);
-  const int slot = __builtin_amdgcn_readfirstlane(wd.y);
-  const int base = __builtin_amdgcn_readfirstlane(wd.z);
-  const int m = __builtin_amdgcn_readfirstlane(wd.w);
+  const SlotRec& W = v.slot_rec[(size_t)blockIdx.x * 8 + wave];  // wave-uniform: scalar loads
+  const int node = W.node, slot = W.slot, base = W.base, m = W.m;
   const bool active = node >= 0;
   uint32_t fl = 0;
-  double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0;
+  double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0, co_prev = 0.0, ci_prev = 0.0;
   int lin = 0, lout = 0, kind = 0;
+  double tfr[PEDN_MAX_DEGREE - 1];
 
   if (active) {
-    const int s0 = v.node_slot_ptr[node];
-    kind = v.node_kind[node];
-    lin = v.slot_in[s0 + slot];
-    lout = v.slot_out[s0 + slot];
+    kind = W.kind;
+    lin = W.lin;
+    lout = W.lout;
+    const int turn0 = W.turn0 + slot * (m - 1);
+    const bool static_tf = kind == 1 && !W.dyn;
     if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
-      s_i = v.demand[((size_t)v.node_demand_row[node] * v.T1 + tp) * RS + r];
+      s_i = v.demand[((size_t)W.demand_row * v.T1 + tp) * RS + r];
+      co_prev = v.f64[F_CO][at(tp, lin, Lall, RS, r)];
+      ci_prev = v.f64[F_CI][at(tp, lout, Lall, RS, r)];
+      if (static_tf) {
+        const bool shared = v.tf_u[turn0] == v.tf_u[turn0];  // not NaN
+#pragma unroll
+        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
+          if (jj < m - 1) tfr[jj] = shared ? v.tf_u[turn0 + jj] : v.tf[(size_t)(turn0 + jj) * RS + r];
+      }
       r_i = 1e6;
     } else {
-      const LinkP Pin = v.lp[lin];
-      const LinkP Pout = v.lp[lout];
-      float n_in = v.f32[G_N][at(tp, lin, L, RS, r)];
-      float n_out = v.f32[G_N][at(tp, lout, L, RS, r)];
-      s_i = send_flow(v, Pin, lin, tp, r, n_in, n_out, fl);
+      const LinkP& Pin = W.Pin;
+      const LinkP& Pout = W.Pout;
+      const bool early = tp < Pin.fft;  // link.py:267-269: sending flow is 0 until the first pedestrians can arrive
+      uint32_t flw = 0;
+      const int tm1 = wrap_idx(tp - 1, v.T1, flw);
+      fl |= flw;
+      // ---- one batch of independent loads (see SlotIn)
+      SlotIn x;
+      x.n_in = v.f32[G_N][at(tp, lin, L, RS, r)];
+      x.n_out = early ? 0.0f : v.f32[G_N][at(tp, lout, L, RS, r)];
+      x.k_in = early ? 0.0f : v.f32[G_K][at(tp, lin, L, RS, r)];
+      x.att_in = early ? 0.0f : v.f32[G_ATT][at(tp, lin, L, RS, r)];
+      x.co_in = v.f64[F_CO][at(tp, lin, Lall, RS, r)];
+      x.s_prev = early ? 0.0 : v.f64[F_S][at(tm1, lin, L, RS, r)];
+      const double fu = v.front_u[lin], bu = v.back_u[lout];
+      x.front_in = early ? 0.0 : (fu == fu ? fu : v.front[(size_t)lin * RS + r]);
+      x.sepw_in = (!early && Pin.sep) ? v.sepw[(size_t)lin * RS + r] : 0.0;
+      x.co_sw = (tp + 1 - Pout.tau_sw >= 0) ? v.f64[F_CO][at(tp + 1 - Pout.tau_sw, lout, Lall, RS, r)] : 0.0;
+      x.ci_out = v.f64[F_CI][at(tp, lout, Lall, RS, r)];
+      x.r_prev = v.f64[F_R][at(tm1, lout, L, RS, r)];
+      x.back_out = bu == bu ? bu : v.back[(size_t)lout * RS + r];
+      x.sepw_out = Pout.sep ? v.sepw[(size_t)lout * RS + r] : 0.0;
+      if (static_tf) {
+        const bool shared = v.tf_u[turn0] == v.tf_u[turn0];  // not NaN
+#pragma unroll
+        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
+          if (jj < m - 1) tfr[jj] = shared ? v.tf_u[turn0 + jj] : v.tf[(size_t)(turn0 + jj) * RS + r];
+      }
+      co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
+      ci_prev = x.ci_out;  // cumulative_inflow[t-1] of the outgoing link
+      s_i = early ? 0.0 : send_flow(v, Pin, lin, tp, r, x, fl);
+      v.f64[F_S][at(tp, lin, L, RS, r)] = s_i;  // link.py:268,367
       if (s_i < 0.0) fl |= PEDN_F_NEG_FLOW;
-      r_i = recv_flow(v, Pout, lout, tp, r, n_in, s_i, fl);
+      r_i = recv_flow(v, Pout, lout, tp, r, x, s_i, fl);
       v.f64[F_R][at(tp, lout, L, RS, r)] = r_i;  // node.py:206
     }
     if (s_i < 0.0 || r_i < 0.0) fl |= PEDN_F_NEG_FLOW;
 
     if (kind == 1) {
       // turning fractions of row `slot`: static, or recomputed from the route-choice tables (path_finder.py:591-715)
-      const int turn0 = v.node_turn_ptr[node] + slot * (m - 1);
-      double tfr[PEDN_MAX_DEGREE - 1];
-      if (v.node_dyn[node]) {
+      if (W.dyn) {
         // tf[turn] = sum over the turn's (od) products P(down | up, od) * P(od | up)   (path_finder.py:668-686).
         // The products of one row are contiguous: probabilities were stored in pair order by turn_prob_kernel and
         // P(od | up) (replica independent, :599-615) was tabulated per pair and step on the host.
@@ -331,10 +378,6 @@ __global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
             v.tf[(size_t)(turn0 + jj) * RS + r] = tfr[jj];
           }
         }
-      } else {
-#pragma unroll
-        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
-          if (jj < m - 1) tfr[jj] = v.tf[(size_t)(turn0 + jj) * RS + r];
       }
       // P[i][j] * s_i  (node.py:285)
 #pragma unroll
@@ -394,9 +437,9 @@ __global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
     }
     // Node.update_links (node.py:146-162; link.py:19-25)
     v.f64[F_OUT][at(t, lin, Lall, RS, r)] = qo;
-    v.f64[F_CO][at(t, lin, Lall, RS, r)] = v.f64[F_CO][at(t - 1, lin, Lall, RS, r)] + qo;
+    v.f64[F_CO][at(t, lin, Lall, RS, r)] = co_prev + qo;
     v.f64[F_IN][at(t, lout, Lall, RS, r)] = qi;
-    v.f64[F_CI][at(t, lout, Lall, RS, r)] = v.f64[F_CI][at(t - 1, lout, Lall, RS, r)] + qi;
+    v.f64[F_CI][at(t, lout, Lall, RS, r)] = ci_prev + qi;
     if (fl) atomicOr(&v.flags[r], fl);
   }
 }
@@ -446,7 +489,8 @@ __device__ __forceinline__ void speed_update(const DevView& v, const LinkP& P, i
     v.f32[G_ATT][at(t, l, L, RS, r)] = rs / (float)v.W;
   }
   v.rsum[(size_t)l * RS + r] = rs;
-  v.f64[F_GATE][at(t, l, L, RS, r)] = live_width;  // link.py:188 / :451-452
+  // link.py:188 / :451-452; the record is initialised to `width` (link.py:56), so an unchanged gate needs no store
+  if (live_width != P.width) v.f64[F_GATE][at(t, l, L, RS, r)] = live_width;
 }
 
 // Network.update_link_states (network.py:257-264): both directions of one corridor per lane
@@ -456,10 +500,10 @@ __global__ __launch_bounds__(256, 8) void link_kernel(DevView v, int t) {
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
   int r = (int)(gid % (size_t)RS);
   if (p >= v.n_pairs_corr) return;
-  const int a = v.pair_a[p];
-  const LinkP Pa = v.lp[a];
-  const int b = Pa.rev;
-  const LinkP Pb = v.lp[b];
+  const CorrRec& C = v.corr_rec[p];  // wave-uniform
+  const int a = C.a, b = C.b;
+  const LinkP& Pa = C.Pa;
+  const LinkP& Pb = C.Pb;
   // link.py:133-136
   double da = v.f64[F_IN][at(t, a, Lall, RS, r)] - v.f64[F_OUT][at(t, a, Lall, RS, r)];
   double db = v.f64[F_IN][at(t, b, Lall, RS, r)] - v.f64[F_OUT][at(t, b, Lall, RS, r)];
@@ -474,8 +518,9 @@ __global__ __launch_bounds__(256, 8) void link_kernel(DevView v, int t) {
   v.f32[G_N][at(t, b, L, RS, r)] = nb;
   v.f32[G_K][at(t, a, L, RS, r)] = ka;
   v.f32[G_K][at(t, b, L, RS, r)] = kb;
-  speed_update(v, Pa, a, t, r, ka, kb, Pa.sep ? wa : v.back[(size_t)a * RS + r]);
-  speed_update(v, Pb, b, t, r, kb, ka, Pb.sep ? wb : v.back[(size_t)b * RS + r]);
+  const double bua = v.back_u[a], bub = v.back_u[b];
+  speed_update(v, Pa, a, t, r, ka, kb, Pa.sep ? wa : (bua == bua ? bua : v.back[(size_t)a * RS + r]));
+  speed_update(v, Pb, b, t, r, kb, ka, Pb.sep ? wb : (bub == bub ? bub : v.back[(size_t)b * RS + r]));
 }
 
 // ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------
@@ -657,6 +702,10 @@ struct pedn_sim {
   double* d_turn_tab = nullptr;
   RlView rl{};
   bool rl_ready = false;
+  std::vector<double> h_front_u, h_back_u, h_tf_u;
+  double *d_front_u = nullptr, *d_back_u = nullptr, *d_tf_u = nullptr;
+  std::vector<int32_t> h_node_dyn;
+  std::vector<char> h_rl_link;  // links whose widths the RL action kernel writes per replica: never uniform
   int n_pair = 0, n_up = 0;
   std::vector<void*> allocs;
   void* stage = nullptr;
@@ -719,6 +768,19 @@ static int reset_state(pedn_sim* s) {
     hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s->stream, v);
     HIP_TRY(s, hipGetLastError());
   }
+  return PEDN_OK;
+}
+
+static int push_uniform(pedn_sim* s) {
+  for (size_t l = 0; l < s->h_rl_link.size(); ++l)
+    if (s->h_rl_link[l]) s->h_front_u[l] = s->h_back_u[l] = __builtin_nan("");
+  if (!s->h_front_u.empty()) {
+    HIP_TRY(s, hipMemcpyAsync(s->d_front_u, s->h_front_u.data(), s->h_front_u.size() * 8, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(s, hipMemcpyAsync(s->d_back_u, s->h_back_u.data(), s->h_back_u.size() * 8, hipMemcpyHostToDevice, s->stream));
+  }
+  if (!s->h_tf_u.empty())
+    HIP_TRY(s, hipMemcpyAsync(s->d_tf_u, s->h_tf_u.data(), s->h_tf_u.size() * 8, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));  // the host vectors may change right after
   return PEDN_OK;
 }
 
@@ -909,11 +971,15 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   TRY(upload(s, m->turn_pair_ptr, m->n_turns + 1, &v.turn_pair_ptr));
   TRY(upload(s, m->od_w, (size_t)m->n_od * v.T1, &v.od_w));
   {  // corridors: one lane of link_kernel updates both directions
-    std::vector<int32_t> pa;
+    std::vector<CorrRec> cr;
     for (int l = 0; l < L; ++l)
-      if (l < m->link_rev[l]) pa.push_back(l);
-    v.n_pairs_corr = (int)pa.size();
-    TRY(upload(s, pa.data(), pa.size(), &v.pair_a));
+      if (l < m->link_rev[l]) {
+        CorrRec c{};
+        c.a = l; c.b = m->link_rev[l]; c.Pa = lp[c.a]; c.Pb = lp[c.b];
+        cr.push_back(c);
+      }
+    v.n_pairs_corr = (int)cr.size();
+    TRY(upload(s, cr.data(), cr.size(), &v.corr_rec));
   }
   {  // bin nodes into blocks of 8 waves (first-fit decreasing on the slot count)
     std::vector<int> order(N);
@@ -930,17 +996,28 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       bins[chosen].push_back(n);
       fill[chosen] += d;
     }
-    std::vector<int4> wd(bins.size() * 8, make_int4(-1, 0, 0, 0));
+    SlotRec idle{};
+    idle.node = -1;
+    std::vector<SlotRec> rec(bins.size() * 8, idle);
     for (size_t b = 0; b < bins.size(); ++b) {
       int wave = 0, base = 0;
       for (int n : bins[b]) {
         int d = deg(n);
-        for (int k = 0; k < d; ++k) wd[b * 8 + wave++] = make_int4(n, k, base, d);
+        for (int k = 0; k < d; ++k) {
+          SlotRec& R = rec[b * 8 + wave++];
+          R.node = n; R.slot = k; R.base = base; R.m = d;
+          R.kind = m->node_kind[n]; R.dyn = m->node_dyn[n];
+          R.lin = m->slot_in_link[m->node_slot_ptr[n] + k];
+          R.lout = m->slot_out_link[m->node_slot_ptr[n] + k];
+          R.turn0 = m->node_turn_ptr[n];
+          R.demand_row = m->node_demand_row[n];
+          if (R.lin < L) { R.Pin = lp[R.lin]; R.Pout = lp[R.lout]; }
+        }
         base += d * d;  // <= 64 tiles because sum(d) <= 8
       }
     }
     s->n_blocks = (int)bins.size();
-    TRY(upload(s, wd.data(), wd.size(), &v.wave_desc));
+    TRY(upload(s, rec.data(), rec.size(), &v.slot_rec));
   }
   // ---- dynamic state
   {
@@ -995,6 +1072,20 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       HIP_TRY(s, hipStreamSynchronize(s->stream));
     }
     if (m->n_ent) HIP_TRY(s, hipMemsetAsync(v.ent_p, 0, (size_t)std::max(m->n_pair, m->n_ent) * v.RS * 8, s->stream));
+    // replica-uniform shortcuts: everything starts uniform; dynamic nodes always use their per-replica rows
+    const double qnan = __builtin_nan("");
+    s->h_front_u.assign(m->front_gate0, m->front_gate0 + L);
+    s->h_back_u.assign(m->back_gate0, m->back_gate0 + L);
+    s->h_tf_u.assign(m->tf_init, m->tf_init + m->n_turns);
+    s->h_node_dyn.assign(m->node_dyn, m->node_dyn + N);
+    for (int n = 0; n < N; ++n)
+      if (m->node_dyn[n])
+        for (int k = m->node_turn_ptr[n]; k < m->node_turn_ptr[n + 1]; ++k) s->h_tf_u[k] = qnan;
+    TRY(dalloc(s, (size_t)L, &s->d_front_u));
+    TRY(dalloc(s, (size_t)L, &s->d_back_u));
+    TRY(dalloc(s, (size_t)m->n_turns, &s->d_tf_u));
+    v.front_u = s->d_front_u; v.back_u = s->d_back_u; v.tf_u = s->d_tf_u;
+    TRY(push_uniform(s));
     TRY(tabulate_pair_pod(s));
   }
   {
@@ -1069,7 +1160,11 @@ int pedn_set_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, const
   if (node < 0 || node >= s->n_nodes) return fail(s, PEDN_E_ARG, "node out of range");
   int a = s->node_turn_ptr[node], b = s->node_turn_ptr[node + 1];
   if (n != b - a) return fail(s, PEDN_E_ARG, "turning-fraction count does not match m(m-1)");
-  return push_rows(s, s->v.tf, tf, n, (size_t)a, 1, replica);
+  int rc = push_rows(s, s->v.tf, tf, n, (size_t)a, 1, replica);
+  if (rc != PEDN_OK) return rc;
+  for (int k = 0; k < n; ++k)
+    s->h_tf_u[a + k] = (replica == PEDN_ALL && !s->h_node_dyn[node]) ? tf[k] : __builtin_nan("");
+  return push_uniform(s);
 }
 
 int pedn_get_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, double* tf, int32_t n) {
@@ -1088,7 +1183,10 @@ int pedn_set_width(pedn_sim* s, int32_t which, int32_t link, int32_t replica, do
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (link < 0 || link >= s->v.L || which < 0 || which > 3) return fail(s, PEDN_E_ARG, "link or selector out of range");
   double* dst = which == PEDN_W_FRONT ? s->v.front : which == PEDN_W_BACK ? s->v.back : which == PEDN_W_SEP ? s->v.sepw : s->v.sepnp;
-  return push_rows(s, dst, &value, 1, (size_t)link, 1, replica);
+  int rc = push_rows(s, dst, &value, 1, (size_t)link, 1, replica);
+  if (rc != PEDN_OK || which > PEDN_W_BACK) return rc;
+  (which == PEDN_W_FRONT ? s->h_front_u : s->h_back_u)[link] = replica == PEDN_ALL ? value : __builtin_nan("");
+  return push_uniform(s);
 }
 
 int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
@@ -1107,6 +1205,15 @@ int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst, (const double*)s->stage, v.L,
                      (size_t)0, (size_t)1, v.RS, 0, v.R, 1, v.R);
   HIP_TRY(s, hipGetLastError());
+  if (which <= PEDN_W_BACK) {
+    std::vector<double>& u = which == PEDN_W_FRONT ? s->h_front_u : s->h_back_u;
+    for (int l = 0; l < v.L; ++l) {
+      bool same = true;
+      for (int r = 1; r < v.R && same; ++r) same = values[(size_t)l * v.R + r] == values[(size_t)l * v.R];
+      u[l] = same ? values[(size_t)l * v.R] : __builtin_nan("");
+    }
+    return push_uniform(s);
+  }
   return PEDN_OK;
 }
 
@@ -1305,6 +1412,19 @@ int pedn_rl_configure(pedn_sim* s, const pedn_rl_desc* d, int32_t* n_actions, in
   HIP_TRY(s, hipMemset(q.rew, 0, (size_t)v.R * d->n_agents * sizeof(float)));
   q.n_agents = d->n_agents; q.A = A; q.O = O; q.obs_mode = d->obs_mode; q.normalize = d->normalize; q.reward_mode = d->reward_mode;
   q.fpl = fpl; q.max_delta_sep = d->max_delta_sep; q.max_delta_gate = d->max_delta_gate; q.min_sep = d->min_sep;
+  // widths of controlled links are written per replica by rl_apply_kernel: never take the uniform shortcut for them
+  s->h_rl_link.assign((size_t)v.L, 0);
+  for (int a = 0; a < d->n_agents; ++a)
+    for (int k = d->agent_link_ptr[a]; k < d->agent_link_ptr[a + 1]; ++k) s->h_rl_link[d->agent_links[k]] = 1;
+  {
+    std::vector<LinkP> lp((size_t)v.L);
+    HIP_TRY(s, hipMemcpy(lp.data(), v.lp, lp.size() * sizeof(LinkP), hipMemcpyDeviceToHost));
+    for (int a = 0; a < d->n_agents; ++a)
+      for (int k = d->agent_link_ptr[a]; k < d->agent_link_ptr[a + 1]; ++k) {
+        s->h_rl_link[lp[d->agent_links[k]].rev] = 1;
+      }
+  }
+  if ((rc = push_uniform(s)) != PEDN_OK) return rc;
   s->rl_ready = true;
   if (n_actions) *n_actions = A;
   if (n_obs) *n_obs = O;

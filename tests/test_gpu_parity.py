@@ -225,3 +225,40 @@ def test_c_abi_argument_errors_and_reset():
     with pytest.raises(eng.ModelError):
         net.run(50, 70)
     net.close()
+
+
+def test_per_replica_widths_and_turning_fractions_via_replica_scope():
+    """`with network.replica(r)` scopes setters to one replica (the replica-uniform fast path must fall back to the
+    per-replica rows); every replica is checked against a CPU oracle run with that replica's settings."""
+    g = Golden("forky")
+    R, steps = 6, 120
+    net = build_network(g, n_replicas=R, rng_seed=3)
+    custom_tf = {2: np.array([0.2, 0.8, 0.5, 0.5, 0.9, 0.1]), 4: np.array([1.0, 0.0, 0.3, 0.7, 0.0, 1.0])}
+    gate = {1: 0.4, 4: 0.0}
+    model = flatten_network(net)
+    base_tf = np.array(g.info["tf_values"][0])
+    for r, tf in custom_tf.items():
+        with net.replica(r):
+            net.nodes[1].turning_fractions = tf
+    net.run(1, 40)
+    for r, w in gate.items():
+        with net.replica(r):
+            net.links[(1, 2)].back_gate_width = w
+            assert net.links[(2, 1)].front_gate_width == w
+    assert net.links[(1, 2)].back_gate_width == 1                      # replica 0 untouched
+    net.run(40, steps)
+    e = net._engine
+    for r in range(R):
+        o = od.Oracle(model, seed=3, replica=r)
+        o.set_tf(net.nodes[1].index, custom_tf.get(r, base_tf))
+        o.run(1, 40)
+        if r in gate:
+            o.set_width(1, net.links[(1, 2)].index, gate[r])
+            o.set_width(0, net.links[(2, 1)].index, gate[r])
+        o.run(40, steps)
+        for fname in ALL_FIELDS:
+            mine = e.read_block(LINK_FIELDS[fname][0], 0, steps, rep0=r, rep1=r + 1)[:, :, 0].T
+            assert np.array_equal(mine[:e.n_links], o.field(fname)[:e.n_links, :steps]), (r, fname)
+        with net.replica(r):
+            assert np.array_equal(net.nodes[1].turning_fractions, custom_tf.get(r, base_tf))
+    net.close()
