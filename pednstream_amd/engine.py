@@ -78,6 +78,13 @@ def build_model_desc(model: dict):
 
 def _load():
     if not os.path.exists(LIB_PATH):
+        # build on demand when the toolchain is there (same recipe as __graft_entry__.build()); never a CPU fallback
+        import shutil
+        import subprocess
+
+        if shutil.which("make") and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+            subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "libpedn_hip.so"], check=False)
+    if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"HIP engine library not built: {LIB_PATH} is missing. Run `python -c 'import "
                            f"__graft_entry__ as g; g.build()'` or `make -C pednstream_amd/csrc` (needs hipcc). "
                            f"There is no CPU fallback for the product path.")
