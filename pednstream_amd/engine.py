@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpedn_hip.so")
+LIB_PATH = os.environ.get("PEDN_HIP_LIB") or os.path.join(_HERE, "csrc", "libpedn_hip.so")   # env override: A/B builds
 
 PEDN_ALL = -1
 ABI_VERSION = 1
