@@ -243,6 +243,24 @@ SEP_PARAMS = {
 }
 
 
+# A hub with 7 neighbours that is also an origin: 8 slots, the largest node the kernels support (PEDN_MAX_DEGREE).
+STAR_N = 15
+STAR_ADJ = [[0] * STAR_N for _ in range(STAR_N)]
+for _k in range(1, 8):
+    STAR_ADJ[0][_k] = STAR_ADJ[_k][0] = 1                  # hub 0 -- spokes 1..7
+    STAR_ADJ[_k][_k + 7] = STAR_ADJ[_k + 7][_k] = 1          # spoke k -- leaf k+7
+STAR_ADJ[1][2] = STAR_ADJ[2][1] = 1                        # one chord so that several routes exist
+STAR_PARAMS = {
+    "unit_time": 10, "simulation_steps": 260, "assign_flows_type": "classic", "seed": 5,
+    "path_finder": {"k_paths": 3, "temp": 4.0, "alpha": 1.0, "beta": 0.6, "omega": 0.7},
+    "default_link": {"length": 60, "width": 2.0, "free_flow_speed": 1.3, "k_critical": 1.8, "k_jam": 5.5, "gamma": 0.01,
+                     "speed_noise_std": 0.04, "fd_type": "yperman", "bi_factor": 1, "activity_probability": 0.1},
+    "links": {"0_3": {"length": 45, "width": 1.2}, "0_5": {"length": 75}},
+    "demand": {"origin_0": {"peak_lambda": 30, "base_lambda": 22}, "origin_8": {"peak_lambda": 25, "base_lambda": 12},
+               "origin_12": {"peak_lambda": 20, "base_lambda": 15}},
+}
+
+
 def replica_demand(T, r, base=20.0, peak=25.0):
     """Config #2 per-replica origin demand: Poisson around the gaussian-peaks profile, numpy Generator(1000+r)."""
     t = np.arange(T)
@@ -266,6 +284,7 @@ CASES = {
     "forky": lambda: direct_case("forky", FORKY_ADJ, FORKY_PARAMS, [0, 4], tf_nodes=[1],
                                  tf_values=[[1, 0, 0.5, 0.5, 0, 1]],
                                  mutations=[(40, "back_gate_set", 1, 2, 0.0), (120, "back_gate_set", 1, 2, 1.0)]),
+    "star8": lambda: direct_case("star8", STAR_ADJ, STAR_PARAMS, [0, 8, 12], destination_nodes=[9, 10, 11, 13, 14, 0], seed=21, replica=2),
     "odd_params": lambda: direct_case("odd_params", ODD_ADJ, ODD_PARAMS, [0, 6], destination_nodes=[6, 0], seed=11, replica=5),
     "odd_separators": lambda: direct_case("odd_separators", SEP_ADJ, SEP_PARAMS, [0, 4], seed=2, replica=9,
                                           mutations=[(60, "separator_set", 1, 2, 0.9), (140, "separator_set", 2, 3, 2.4),
