@@ -260,10 +260,13 @@ class Engine:
         msg = "; ".join(text for bit, text in ERROR_BITS.items() if bits & bit)
         msg = f"replica {bad}: {msg}"
         if bits & (1 | 8):
-            raise ValueError(msg)
-        if bits & 4:
-            raise IndexError(msg)
-        raise ModelError(msg, flags)
+            err = ValueError(msg)
+        elif bits & 4:
+            err = IndexError(msg)
+        else:
+            err = ModelError(msg, flags)
+        err.flags = flags
+        raise err
 
     def profile_step(self, t):
         """One step with per-kernel HIP-event timing: (turn_prob_ms, node_ms, link_ms)."""
