@@ -1438,10 +1438,11 @@ int pedn_rl_apply_actions(pedn_sim* s, const double* actions, int32_t on_device)
   DevView& v = s->v;
   RlView& q = s->rl;
   const size_t bytes = (size_t)v.R * q.A * sizeof(double);
-  if (actions != q.actions)
-    HIP_TRY(s, hipMemcpyAsync(q.actions, actions, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->stream));
+  RlView qq = q;
+  if (on_device) qq.actions = const_cast<double*>(actions);  // read the caller's rows in place: no staging copy
+  else HIP_TRY(s, hipMemcpyAsync(q.actions, actions, bytes, hipMemcpyHostToDevice, s->stream));
   size_t n = (size_t)q.A * v.RS;
-  hipLaunchKernelGGL(rl_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, q);
+  hipLaunchKernelGGL(rl_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, qq);
   HIP_TRY(s, hipGetLastError());
   if (!on_device) HIP_TRY(s, hipStreamSynchronize(s->stream));  // the host buffer is borrowed for the call only
   return PEDN_OK;
