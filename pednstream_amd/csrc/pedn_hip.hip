@@ -275,9 +275,11 @@ __global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
   const int RS = v.RS, L = v.L, Lall = v.Lall;
-  const int r = (int)blockIdx.y * 64 + lane;
+  // blockIdx.x = replica group (fastest in dispatch order): blocks launched together touch neighbouring 512-byte chunks
+  // of the same history rows
+  const int r = (int)blockIdx.x * 64 + lane;
   const int tp = t - 1;
-  const SlotRec& W = v.slot_rec[(size_t)blockIdx.x * 8 + wave];  // wave-uniform: scalar loads
+  const SlotRec& W = v.slot_rec[(size_t)blockIdx.y * 8 + wave];  // wave-uniform: scalar loads
   const int node = W.node, slot = W.slot, base = W.base, m = W.m;
   const bool active = node >= 0;
   uint32_t fl = 0;
@@ -1236,7 +1238,7 @@ static int launch_step(pedn_sim* s, int t) {
     size_t n = (size_t)v.n_multi * v.RS;
     hipLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
   }
-  hipLaunchKernelGGL(node_kernel, dim3((unsigned)s->n_blocks, rgroups), dim3(512), 0, s->stream, v, t);
+  hipLaunchKernelGGL(node_kernel, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, v, t);
   if (v.n_pairs_corr > 0) {
     size_t n = (size_t)v.n_pairs_corr * v.RS;
     hipLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
@@ -1267,7 +1269,7 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
     size_t n = (size_t)v.n_multi * v.RS;
     hipExtLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
   }
-  hipExtLaunchKernelGGL(node_kernel, dim3((unsigned)s->n_blocks, rgroups), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
+  hipExtLaunchKernelGGL(node_kernel, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
   if (v.n_pairs_corr > 0) {
     size_t n = (size_t)v.n_pairs_corr * v.RS;
     hipExtLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[4], ev[5], 0, v, t);
