@@ -1,7 +1,7 @@
 // pedn_hip.hip -- MI355X (gfx950) engine for PedNStream's network_loading hot path: HIP kernels + C-ABI (include/pedn.h).
 //
 // Data layout in HBM: every history field is one array [T+1][columns][RS] with the replica index
-// fastest (RS = replicas rounded up to a multiple of 64).  A wavefront therefore owns 64 consecutive replicas of ONE
+// fastest (RS = replicas rounded up to a multiple of 128).  A wavefront therefore owns 64 consecutive replicas of ONE
 // link or node: topology and link parameters are wave-uniform (scalar loads), every history access of a wave is
 // one coalesced 256/512-byte row segment, and the data-dependent look-backs (cumulative_inflow[t+1-tau],
 // inflow[t-tau-k]) gather between rows of the same column.
@@ -446,10 +446,11 @@ __global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
   }
 }
 
-// BiDirectionalFd.__call__ + the travel-time part of Link.update_speeds for one direction
-__device__ __forceinline__ void speed_update(const DevView& v, const LinkP& P, int l, int t, int r, float ks, float ko,
-                                             double live_width) {
-  const int L = v.L, RS = v.RS;
+// BiDirectionalFd.__call__ + the travel-time part of Link.update_speeds for one direction and one replica; pure arithmetic
+struct SpeedOut { float spd, tt, lf, att, rs; };
+
+__device__ __forceinline__ SpeedOut speed_calc(const DevView& v, const LinkP& P, int l, int t, int r, float ks, float ko,
+                                               float rsum_prev, float tt_old) {
   float ke = P.sep ? ks : ks + (float)P.bi * ko;  // functions.py:113
   bool is64;  // true: the speed is a Python float (binary64) at this point, false: np.float32
   double v64 = 0.0;
@@ -478,51 +479,89 @@ __device__ __forceinline__ void speed_update(const DevView& v, const LinkP& P, i
   }
   if (is64) { if (!(v64 > 0.0)) v64 = 0.0; }
   else if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }
-  float spd = is64 ? (float)v64 : v32;
-  float tt;
-  if (is64) tt = v64 > 0.0 ? (float)(P.length / v64) : (float)(P.length / 0.05);  // link.py:177
-  else tt = (float)P.length / v32;
-  v.f32[G_V][at(t, l, L, RS, r)] = spd;
-  v.f32[G_TT][at(t, l, L, RS, r)] = tt;
-  v.f32[G_LF][at(t, l, L, RS, r)] = ks * spd;  // link.py:181
-  float rs = v.rsum[(size_t)l * RS + r] + tt;   // link.py:183-186, float32 running sum
+  SpeedOut o;
+  o.spd = is64 ? (float)v64 : v32;
+  if (is64) o.tt = v64 > 0.0 ? (float)(P.length / v64) : (float)(P.length / 0.05);  // link.py:177
+  else o.tt = (float)P.length / v32;
+  o.lf = ks * o.spd;               // link.py:181
+  o.rs = rsum_prev + o.tt;         // link.py:183-186, float32 running sum
+  o.att = P.tt0;
   if (t >= v.W) {
-    rs = rs - v.f32[G_TT][at(t - v.W, l, L, RS, r)];
-    v.f32[G_ATT][at(t, l, L, RS, r)] = rs / (float)v.W;
+    o.rs = o.rs - tt_old;
+    o.att = o.rs / (float)v.W;
   }
-  v.rsum[(size_t)l * RS + r] = rs;
-  // link.py:188 / :451-452; the record is initialised to `width` (link.py:56), so an unchanged gate needs no store
-  if (live_width != P.width) v.f64[F_GATE][at(t, l, L, RS, r)] = live_width;
+  return o;
 }
 
-// Network.update_link_states (network.py:257-264): both directions of one corridor per lane
-__global__ __launch_bounds__(256, 8) void link_kernel(DevView v, int t) {
-  const int RS = v.RS, L = v.L, Lall = v.Lall;
+__device__ __forceinline__ double2 ld2(const double* p, size_t i) { return *reinterpret_cast<const double2*>(p + i); }
+__device__ __forceinline__ float2 ld2(const float* p, size_t i) { return *reinterpret_cast<const float2*>(p + i); }
+__device__ __forceinline__ void st2(double* p, size_t i, double a, double b) { *reinterpret_cast<double2*>(p + i) = make_double2(a, b); }
+__device__ __forceinline__ void st2(float* p, size_t i, float a, float b) { *reinterpret_cast<float2*>(p + i) = make_float2(a, b); }
+
+// Network.update_link_states (network.py:257-264).  One lane = both directions of one corridor for TWO adjacent replicas:
+// every history access is a 16-byte (f64) or 8-byte (f32) vector access, i.e. 1 KiB / 512 B per wave instruction.
+__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) {
+  const int RS = v.RS, L = v.L, Lall = v.Lall, H = RS / 2;
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
-  int r = (int)(gid % (size_t)RS);
+  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)H));
+  const int r = 2 * (int)(gid % (size_t)H);
   if (p >= v.n_pairs_corr) return;
   const CorrRec& C = v.corr_rec[p];  // wave-uniform
   const int a = C.a, b = C.b;
   const LinkP& Pa = C.Pa;
   const LinkP& Pb = C.Pb;
-  // link.py:133-136
-  double da = v.f64[F_IN][at(t, a, Lall, RS, r)] - v.f64[F_OUT][at(t, a, Lall, RS, r)];
-  double db = v.f64[F_IN][at(t, b, Lall, RS, r)] - v.f64[F_OUT][at(t, b, Lall, RS, r)];
-  float na = (float)((double)v.f32[G_N][at(t - 1, a, L, RS, r)] + da);
-  float nb = (float)((double)v.f32[G_N][at(t - 1, b, L, RS, r)] + db);
-  double wa = Pa.sep ? v.sepw[(size_t)a * RS + r] : Pa.width;
-  double wb = Pb.sep ? v.sepw[(size_t)b * RS + r] : Pb.width;
-  // a separator width held as np.float64 turns the division into binary64 (PEDN_W_SEP_NUMPY)
-  float ka = (Pa.sep && v.sepnp[(size_t)a * RS + r] != 0.0) ? (float)((double)na / (Pa.length * wa)) : na / (float)(Pa.length * wa);
-  float kb = (Pb.sep && v.sepnp[(size_t)b * RS + r] != 0.0) ? (float)((double)nb / (Pb.length * wb)) : nb / (float)(Pb.length * wb);
-  v.f32[G_N][at(t, a, L, RS, r)] = na;
-  v.f32[G_N][at(t, b, L, RS, r)] = nb;
-  v.f32[G_K][at(t, a, L, RS, r)] = ka;
-  v.f32[G_K][at(t, b, L, RS, r)] = kb;
+  const bool win = t >= v.W;
+  // ---- loads
+  const double2 ina = ld2(v.f64[F_IN], at(t, a, Lall, RS, r)), outa = ld2(v.f64[F_OUT], at(t, a, Lall, RS, r));
+  const double2 inb = ld2(v.f64[F_IN], at(t, b, Lall, RS, r)), outb = ld2(v.f64[F_OUT], at(t, b, Lall, RS, r));
+  const float2 pa = ld2(v.f32[G_N], at(t - 1, a, L, RS, r)), pb = ld2(v.f32[G_N], at(t - 1, b, L, RS, r));
+  const float2 rsa = ld2(v.rsum, (size_t)a * RS + r), rsb = ld2(v.rsum, (size_t)b * RS + r);
+  const float2 oa = win ? ld2(v.f32[G_TT], at(t - v.W, a, L, RS, r)) : make_float2(0.f, 0.f);
+  const float2 ob = win ? ld2(v.f32[G_TT], at(t - v.W, b, L, RS, r)) : make_float2(0.f, 0.f);
   const double bua = v.back_u[a], bub = v.back_u[b];
-  speed_update(v, Pa, a, t, r, ka, kb, Pa.sep ? wa : (bua == bua ? bua : v.back[(size_t)a * RS + r]));
-  speed_update(v, Pb, b, t, r, kb, ka, Pb.sep ? wb : (bub == bub ? bub : v.back[(size_t)b * RS + r]));
+  double2 wa = make_double2(Pa.width, Pa.width), wb = make_double2(Pb.width, Pb.width), fa = make_double2(0, 0), fb = make_double2(0, 0);
+  if (Pa.sep) { wa = ld2(v.sepw, (size_t)a * RS + r); fa = ld2(v.sepnp, (size_t)a * RS + r); }
+  if (Pb.sep) { wb = ld2(v.sepw, (size_t)b * RS + r); fb = ld2(v.sepnp, (size_t)b * RS + r); }
+  double2 ga = Pa.sep ? wa : make_double2(bua, bua), gb = Pb.sep ? wb : make_double2(bub, bub);  // recorded width (link.py:188 / :451-452)
+  if (!Pa.sep && !(bua == bua)) ga = ld2(v.back, (size_t)a * RS + r);
+  if (!Pb.sep && !(bub == bub)) gb = ld2(v.back, (size_t)b * RS + r);
+  // ---- per replica arithmetic (link.py:133-136, then update_speeds)
+  float na[2], nb[2], ka[2], kb[2];
+  SpeedOut sa[2], sb[2];
+  const double dina[2] = {ina.x - outa.x, ina.y - outa.y}, dinb[2] = {inb.x - outb.x, inb.y - outb.y};
+  const float pav[2] = {pa.x, pa.y}, pbv[2] = {pb.x, pb.y};
+  const double wav[2] = {wa.x, wa.y}, wbv[2] = {wb.x, wb.y}, fav[2] = {fa.x, fa.y}, fbv[2] = {fb.x, fb.y};
+  const float rsav[2] = {rsa.x, rsa.y}, rsbv[2] = {rsb.x, rsb.y}, oav[2] = {oa.x, oa.y}, obv[2] = {ob.x, ob.y};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    na[j] = (float)((double)pav[j] + dina[j]);
+    nb[j] = (float)((double)pbv[j] + dinb[j]);
+    // a separator width held as np.float64 turns the division into binary64 (PEDN_W_SEP_NUMPY)
+    ka[j] = (Pa.sep && fav[j] != 0.0) ? (float)((double)na[j] / (Pa.length * wav[j])) : na[j] / (float)(Pa.length * wav[j]);
+    kb[j] = (Pb.sep && fbv[j] != 0.0) ? (float)((double)nb[j] / (Pb.length * wbv[j])) : nb[j] / (float)(Pb.length * wbv[j]);
+    sa[j] = speed_calc(v, Pa, a, t, r + j, ka[j], kb[j], rsav[j], oav[j]);
+    sb[j] = speed_calc(v, Pb, b, t, r + j, kb[j], ka[j], rsbv[j], obv[j]);
+  }
+  // ---- stores
+  st2(v.f32[G_N], at(t, a, L, RS, r), na[0], na[1]);
+  st2(v.f32[G_N], at(t, b, L, RS, r), nb[0], nb[1]);
+  st2(v.f32[G_K], at(t, a, L, RS, r), ka[0], ka[1]);
+  st2(v.f32[G_K], at(t, b, L, RS, r), kb[0], kb[1]);
+  st2(v.f32[G_V], at(t, a, L, RS, r), sa[0].spd, sa[1].spd);
+  st2(v.f32[G_V], at(t, b, L, RS, r), sb[0].spd, sb[1].spd);
+  st2(v.f32[G_TT], at(t, a, L, RS, r), sa[0].tt, sa[1].tt);
+  st2(v.f32[G_TT], at(t, b, L, RS, r), sb[0].tt, sb[1].tt);
+  st2(v.f32[G_LF], at(t, a, L, RS, r), sa[0].lf, sa[1].lf);
+  st2(v.f32[G_LF], at(t, b, L, RS, r), sb[0].lf, sb[1].lf);
+  if (win) {
+    st2(v.f32[G_ATT], at(t, a, L, RS, r), sa[0].att, sa[1].att);
+    st2(v.f32[G_ATT], at(t, b, L, RS, r), sb[0].att, sb[1].att);
+  }
+  st2(v.rsum, (size_t)a * RS + r, sa[0].rs, sa[1].rs);
+  st2(v.rsum, (size_t)b * RS + r, sb[0].rs, sb[1].rs);
+  // the record is initialised to `width` (link.py:56), so an unchanged gate needs no store
+  if (ga.x != Pa.width || ga.y != Pa.width) st2(v.f64[F_GATE], at(t, a, L, RS, r), ga.x, ga.y);
+  if (gb.x != Pb.width || gb.y != Pb.width) st2(v.f64[F_GATE], at(t, b, L, RS, r), gb.x, gb.y);
 }
 
 // ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------
@@ -865,7 +904,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   v.Lall = L + m->n_vlinks;
   v.T1 = m->T + 1;
   v.R = n_replicas;
-  v.RS = (n_replicas + 63) / 64 * 64;
+  v.RS = (n_replicas + 127) / 128 * 128;  // a link_kernel wave covers 128 replicas (2 per lane), a node_kernel wave 64
   v.W = m->window;
   v.dt = m->dt;
   v.pf_temp = m->pf_temp; v.pf_alpha = m->pf_alpha; v.pf_beta = m->pf_beta; v.pf_omega = m->pf_omega; v.pf_eps = m->pf_eps;
@@ -1240,7 +1279,7 @@ static int launch_step(pedn_sim* s, int t) {
   }
   hipLaunchKernelGGL(node_kernel, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, v, t);
   if (v.n_pairs_corr > 0) {
-    size_t n = (size_t)v.n_pairs_corr * v.RS;
+    size_t n = (size_t)v.n_pairs_corr * (v.RS / 2);
     hipLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
   }
   return PEDN_OK;
@@ -1271,7 +1310,7 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   }
   hipExtLaunchKernelGGL(node_kernel, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
   if (v.n_pairs_corr > 0) {
-    size_t n = (size_t)v.n_pairs_corr * v.RS;
+    size_t n = (size_t)v.n_pairs_corr * (v.RS / 2);
     hipExtLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[4], ev[5], 0, v, t);
   }
   HIP_TRY(s, hipGetLastError());
