@@ -188,6 +188,18 @@ int pedn_profile_step(pedn_sim* sim, int32_t t, float ms[3]);
 /* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */
 int pedn_reset(pedn_sim* sim);
 
+/* ---- per-replica scenarios on one topology (reference: NetworkEnvGenerator.create_network with
+ * link_params_overrides / od_flows / demand_params_overrides, src/utils/env_loader.py:81-158, as produced by
+ * generate_random_link_params :363-424, generate_random_od_flows :224-259, generate_random_demand_params :183-222).
+ * Demand per replica is pedn_set_demand(node, replica, ...).  Call pedn_reset afterwards: travel_time[0] depends on them. */
+/* matrices [n_links][n_replicas]: k_critical, k_jam, free_flow_speed and the host-derived free_flow_tau (link.py:86),
+ * shock-wave look-back (link.py:380) and travel_time[0] (link.py:83).  kc == NULL returns to the shared parameters. */
+int pedn_set_link_params(pedn_sim* sim, const double* kc, const double* kj, const double* vf, const int32_t* free_flow_tau,
+                         const int32_t* tau_sw, const float* tt0);
+/* w[n_od][n_replicas]: time-constant OD weights per replica (the randomiser's np.full(T+1, weight)); NULL returns to the
+ * shared, time-varying weights of pedn_set_od_weights */
+int pedn_set_od_weights_per_replica(pedn_sim* sim, const double* w);
+
 /* ---- batched RL environment step around the hot path ------------------------------------------------
  * Replaces, for every replica at once, the per-env Python glue of the reference's PettingZoo wrapper:
  *   pedn_rl_apply_actions   ActionApplier.apply_all_actions / clip_*_action_value     rl/builders.py:264-352

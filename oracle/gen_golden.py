@@ -100,6 +100,30 @@ def direct_case(case, adj, params, origin_nodes, destination_nodes=(), steps=Non
                                        "mutations": muts})
 
 
+def randomized_case(case, name, rand_seed, steps=None, replica=0, np_seed=20261003):
+    """one scenario drawn by the reference's own randomisers (generate_random_link_params / _od_flows /
+    _demand_params, env_loader.py:183-259,363-424; generate_random_od_nodes is NOT applied -- it changes the topology) and
+    built by the reference's create_network with those overrides.  The overrides are stored so that the other side can
+    apply the same scenario to one replica of a batch."""
+    ref = rh.load_reference()
+    np.random.seed(np_seed)
+    gen = ref["env"].NetworkEnvGenerator()
+    gen.create_network(name)                                  # loads config / network_data
+    link_ov = gen.generate_random_link_params(rand_seed)
+    od_w = gen.generate_random_od_flows(rand_seed)
+    dem_ov = gen.generate_random_demand_params(rand_seed)
+    np.random.seed(np_seed + rand_seed)
+    net = gen.create_network(name, od_flows=od_w, link_params_overrides=link_ov, demand_params_overrides=dem_ov)
+    net, static, state, extras = rh.run_reference(None, steps=steps, seed=0, replica=replica, record_tf=True, network=net)
+    extras["tf"] = tf_matrix(net, extras)
+    def plain(d):
+        return {k: {kk: (vv.item() if hasattr(vv, "item") else vv) for kk, vv in v.items()} for k, v in d.items()}
+    save(case, static, state, extras, {"scenario": name, "seed": 0, "replica": replica, "mode": "philox", "np_seed": np_seed,
+                                       "mutations": [], "randomized": {"rand_seed": rand_seed, "link_params_overrides": plain(link_ov),
+                                                                       "od_flows": {f"{o}_{d}": float(w[0]) for (o, d), w in od_w.items()},
+                                                                       "demand_params_overrides": plain(dem_ov)}})
+
+
 def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_steps=150, seed=0, replica=0,
             np_seed=20261003, action_seed=1):
     """Config #5 caller: the reference's ActionApplier / ObservationBuilder / reward (rl/builders.py,
@@ -294,6 +318,10 @@ CASES.update({
     "output_six_node": lambda: output_case("output_six_node", "od_flow_example",
                                            mutations=[(t, "back_gate_delta", 3, 5, -0.1) for t in range(100, 109)]),
     "output_corridor": lambda: output_case("output_corridor", "long_corridor", mutations=[(150, "separator_set", 2, 3, 1.25)]),
+    "rand_nine_a": lambda: randomized_case("rand_nine_a", "nine_intersections", 11, steps=220, replica=0),
+    "rand_nine_b": lambda: randomized_case("rand_nine_b", "nine_intersections", 12, steps=220, replica=1),
+    "rand_delft_a": lambda: randomized_case("rand_delft_a", "delft", 21, steps=60, replica=0),
+    "rand_delft_b": lambda: randomized_case("rand_delft_b", "delft", 22, steps=60, replica=1),
     "rl_nine_opt3": lambda: rl_case("rl_nine_opt3", "nine_intersections", obs_mode="option3", env_steps=200),
     "rl_nine_opt2n": lambda: rl_case("rl_nine_opt2n", "nine_intersections", obs_mode="option2", normalize=True, env_steps=120, action_seed=2),
     "rl_nine_opt5g2": lambda: rl_case("rl_nine_opt5g2", "nine_intersections", obs_mode="option5", action_gap=2, env_steps=90, action_seed=3),

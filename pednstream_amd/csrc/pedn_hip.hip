@@ -69,6 +69,12 @@ struct DevView {
   // replica shares is one scalar load per wave instead of 8 bytes per lane
   const double *front_u, *back_u;  // [L]
   const double* tf_u;              // [n_turns]
+  // per-replica scenario parameters (randomised ensembles / RL resets, env_loader.py:363-424); used when pr != 0
+  const double *kc_r, *kj_r, *vf_r;   // [L][RS] k_critical, k_jam, free_flow_speed
+  const int32_t *fft_r, *tausw_r;     // [L][RS] free_flow_tau, shock-wave look-back
+  const float* tt0_r;                 // [L][RS] travel_time[0]
+  const double *pair_pod_r, *turn_tab_r;  // [n_pair][RS], [n_turns][RS]: P(od | up) with per-replica, time-constant OD weights
+  int32_t pr, pod_pr;
   const double* od_w;
   uint32_t* flags;
   const LinkP* lp;
@@ -92,6 +98,19 @@ __device__ __forceinline__ size_t at(int t, int col, int cols, int RS, int r) {
   return ((size_t)t * (size_t)cols + (size_t)col) * (size_t)RS + (size_t)r;
 }
 __device__ __forceinline__ float clip01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+// Link parameters as seen by one lane: the shared record, or (PR) the replica's own k_critical / k_jam / free-flow speed
+// and the quantities derived from them on the host.
+template <bool PR>
+__device__ __forceinline__ LinkP lane_params(const DevView& v, const LinkP& P, int l, int r) {
+  LinkP Q = P;
+  if (PR) {
+    const size_t i = (size_t)l * v.RS + r;
+    Q.kc = v.kc_r[i]; Q.kj = v.kj_r[i]; Q.vf = v.vf_r[i];
+    Q.fft = v.fft_r[i]; Q.tau_sw = v.tausw_r[i]; Q.tt0 = v.tt0_r[i];
+  }
+  return Q;
+}
+
 __device__ __forceinline__ int wrap_idx(int i, int T1, uint32_t& fl) {
   if (i < 0) i += T1;
   if (i < 0 || i >= T1) { fl |= PEDN_F_INDEX; return 0; }
@@ -207,6 +226,7 @@ __device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int
 // ------------------------------------------------------------------------------------------------- kernels
 // P(down | up, od) for every softmax group with more than one downstream (update_node_turn_probs, path_finder.py:561-589).
 // A group with a single downstream has P = e/e = 1 exactly; those are constants and never recomputed.
+template <bool PR>
 __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
   const int RS = v.RS;
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,7 +249,10 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
         if (E.sep) kf[e] = v.f32[G_K][at(t - 1, E.link, v.L, RS, r)];  // Separator.get_density, link.py:427-428
         else kf[e] = (v.f32[G_N][at(t - 1, E.link, v.L, RS, r)] + v.f32[G_N][at(t - 1, E.rev, v.L, RS, r)]) / E.area32;
         double c = v.f64[F_R][at(t2, E.link, v.L, RS, r)];
-        if (!(c >= 0.0)) c = v.back[(size_t)E.link * RS + r] * E.vf * E.kc * v.dt;  // :575-576
+        if (!(c >= 0.0)) {
+          const double vf = PR ? v.vf_r[(size_t)E.link * RS + r] : E.vf, kc = PR ? v.kc_r[(size_t)E.link * RS + r] : E.kc;
+          c = v.back[(size_t)E.link * RS + r] * vf * kc * v.dt;  // :575-576
+        }
         cap[e] = c;
       } else {
         kf[e] = 0.0f;
@@ -269,6 +292,7 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
 }
 
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
+template <bool PR>
 __global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
   __shared__ double sPS[64 * 64];  // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
   __shared__ double sR[8 * 64];    // receiving flow of each wave's outgoing link
@@ -305,8 +329,8 @@ __global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
       }
       r_i = 1e6;
     } else {
-      const LinkP& Pin = W.Pin;
-      const LinkP& Pout = W.Pout;
+      const LinkP Pin = lane_params<PR>(v, W.Pin, lin, r);
+      const LinkP Pout = lane_params<PR>(v, W.Pout, lout, r);
       const bool early = tp < Pin.fft;  // link.py:267-269: sending flow is 0 until the first pedestrians can arrive
       uint32_t flw = 0;
       const int tm1 = wrap_idx(tp - 1, v.T1, flw);
@@ -350,23 +374,24 @@ __global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
         // The products of one row are contiguous: probabilities were stored in pair order by turn_prob_kernel and
         // P(od | up) (replica independent, :599-615) was tabulated per pair and step on the host.
         const double* pod = v.pair_pod + (size_t)t * v.n_pair;
+        const bool ppr = v.pod_pr != 0;  // per-replica OD weights: tables indexed [product][replica] instead of [step][product]
         double rowsum = 0.0;
 #pragma unroll
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
           if (jj < m - 1) {
             double acc = 0.0;
             const int q1 = v.turn_mode[turn0 + jj] ? 0 : v.turn_pair_ptr[turn0 + jj + 1];
-            if (v.turn_mode[turn0 + jj]) acc = v.turn_tab[(size_t)t * v.n_turns + turn0 + jj];
+            if (v.turn_mode[turn0 + jj]) acc = ppr ? v.turn_tab_r[(size_t)(turn0 + jj) * RS + r] : v.turn_tab[(size_t)t * v.n_turns + turn0 + jj];
             for (int q = v.turn_pair_ptr[turn0 + jj]; q < q1; q += 4) {
               // loads first (independent), then the strictly sequential sum the reference performs
               double e0 = v.pair_const[q] ? 1.0 : v.ent_p[(size_t)q * RS + r];
               double e1 = q + 1 < q1 ? (v.pair_const[q + 1] ? 1.0 : v.ent_p[(size_t)(q + 1) * RS + r]) : 0.0;
               double e2 = q + 2 < q1 ? (v.pair_const[q + 2] ? 1.0 : v.ent_p[(size_t)(q + 2) * RS + r]) : 0.0;
               double e3 = q + 3 < q1 ? (v.pair_const[q + 3] ? 1.0 : v.ent_p[(size_t)(q + 3) * RS + r]) : 0.0;
-              acc += e0 * pod[q];
-              if (q + 1 < q1) acc += e1 * pod[q + 1];
-              if (q + 2 < q1) acc += e2 * pod[q + 2];
-              if (q + 3 < q1) acc += e3 * pod[q + 3];
+              acc += e0 * (ppr ? v.pair_pod_r[(size_t)q * RS + r] : pod[q]);
+              if (q + 1 < q1) acc += e1 * (ppr ? v.pair_pod_r[(size_t)(q + 1) * RS + r] : pod[q + 1]);
+              if (q + 2 < q1) acc += e2 * (ppr ? v.pair_pod_r[(size_t)(q + 2) * RS + r] : pod[q + 2]);
+              if (q + 3 < q1) acc += e3 * (ppr ? v.pair_pod_r[(size_t)(q + 3) * RS + r] : pod[q + 3]);
             }
             tfr[jj] = acc;
             rowsum = (jj == 0) ? acc : rowsum + acc;
@@ -564,6 +589,38 @@ __global__ __launch_bounds__(256) void link_kernel(DevView v, int t) {
   if (gb.x != Pb.width || gb.y != Pb.width) st2(v.f64[F_GATE], at(t, b, L, RS, r), gb.x, gb.y);
 }
 
+// Same update with per-replica link parameters: one replica per lane (the parameters live in vector registers).
+__global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) {
+  const int RS = v.RS, L = v.L, Lall = v.Lall;
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
+  const int r = (int)(gid % (size_t)RS);
+  if (p >= v.n_pairs_corr) return;
+  const CorrRec& C = v.corr_rec[p];
+  const int a = C.a, b = C.b;
+  const LinkP Pa = lane_params<true>(v, C.Pa, a, r), Pb = lane_params<true>(v, C.Pb, b, r);
+  const bool win = t >= v.W;
+  const double da = v.f64[F_IN][at(t, a, Lall, RS, r)] - v.f64[F_OUT][at(t, a, Lall, RS, r)];
+  const double db = v.f64[F_IN][at(t, b, Lall, RS, r)] - v.f64[F_OUT][at(t, b, Lall, RS, r)];
+  const float na = (float)((double)v.f32[G_N][at(t - 1, a, L, RS, r)] + da), nb = (float)((double)v.f32[G_N][at(t - 1, b, L, RS, r)] + db);
+  const double wa = Pa.sep ? v.sepw[(size_t)a * RS + r] : Pa.width, wb = Pb.sep ? v.sepw[(size_t)b * RS + r] : Pb.width;
+  const float ka = (Pa.sep && v.sepnp[(size_t)a * RS + r] != 0.0) ? (float)((double)na / (Pa.length * wa)) : na / (float)(Pa.length * wa);
+  const float kb = (Pb.sep && v.sepnp[(size_t)b * RS + r] != 0.0) ? (float)((double)nb / (Pb.length * wb)) : nb / (float)(Pb.length * wb);
+  const float oa = win ? v.f32[G_TT][at(t - v.W, a, L, RS, r)] : 0.0f, ob = win ? v.f32[G_TT][at(t - v.W, b, L, RS, r)] : 0.0f;
+  const SpeedOut sa = speed_calc(v, Pa, a, t, r, ka, kb, v.rsum[(size_t)a * RS + r], oa);
+  const SpeedOut sb = speed_calc(v, Pb, b, t, r, kb, ka, v.rsum[(size_t)b * RS + r], ob);
+  const double ga = Pa.sep ? wa : v.back[(size_t)a * RS + r], gb = Pb.sep ? wb : v.back[(size_t)b * RS + r];
+  v.f32[G_N][at(t, a, L, RS, r)] = na; v.f32[G_N][at(t, b, L, RS, r)] = nb;
+  v.f32[G_K][at(t, a, L, RS, r)] = ka; v.f32[G_K][at(t, b, L, RS, r)] = kb;
+  v.f32[G_V][at(t, a, L, RS, r)] = sa.spd; v.f32[G_V][at(t, b, L, RS, r)] = sb.spd;
+  v.f32[G_TT][at(t, a, L, RS, r)] = sa.tt; v.f32[G_TT][at(t, b, L, RS, r)] = sb.tt;
+  v.f32[G_LF][at(t, a, L, RS, r)] = sa.lf; v.f32[G_LF][at(t, b, L, RS, r)] = sb.lf;
+  if (win) { v.f32[G_ATT][at(t, a, L, RS, r)] = sa.att; v.f32[G_ATT][at(t, b, L, RS, r)] = sb.att; }
+  v.rsum[(size_t)a * RS + r] = sa.rs; v.rsum[(size_t)b * RS + r] = sb.rs;
+  if (ga != Pa.width) v.f64[F_GATE][at(t, a, L, RS, r)] = ga;
+  if (gb != Pb.width) v.f64[F_GATE][at(t, b, L, RS, r)] = gb;
+}
+
 // ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------
 struct RlView {
   const int32_t *agent_type, *agent_link_ptr, *agent_links, *agent_act_off, *agent_obs_off;
@@ -625,7 +682,7 @@ __global__ void rl_observe_kernel(DevView v, RlView q, int t, int accumulate) {
     float dens_all[PEDN_MAX_DEGREE];
     for (int i = 0; i < n; ++i) {
       const int l = q.agent_links[la + i];
-      const LinkP P = v.lp[l];
+      const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
       const float in_l = (float)v.f64[F_IN][at(t, l, Lall, RS, r)], out_l = (float)v.f64[F_OUT][at(t, l, Lall, RS, r)];
       const float in_r = (float)v.f64[F_IN][at(t, P.rev, Lall, RS, r)], out_r = (float)v.f64[F_OUT][at(t, P.rev, Lall, RS, r)];
       const float dens = dens_at(v, P, l, t, r);
@@ -673,7 +730,7 @@ __global__ void init_state_kernel(DevView v) {
   int r = (int)(gid % RS);
   int l = (int)((gid / RS) % L);
   int t = (int)(gid / ((size_t)RS * L));
-  const LinkP P = v.lp[l];
+  const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
   v.f64[F_S][gid] = -1.0;
   v.f64[F_R][gid] = -1.0;
   v.f64[F_GATE][gid] = P.width;  // link.py:56
@@ -746,7 +803,10 @@ struct pedn_sim {
   std::vector<double> h_front_u, h_back_u, h_tf_u;
   double *d_front_u = nullptr, *d_back_u = nullptr, *d_tf_u = nullptr;
   std::vector<int32_t> h_node_dyn;
-  std::vector<char> h_rl_link;  // links whose widths the RL action kernel writes per replica: never uniform
+  std::vector<char> h_rl_link;
+  double *d_kc_r = nullptr, *d_kj_r = nullptr, *d_vf_r = nullptr, *d_pair_pod_r = nullptr, *d_turn_tab_r = nullptr;
+  int32_t *d_fft_r = nullptr, *d_tausw_r = nullptr;
+  float* d_tt0_r = nullptr;  // links whose widths the RL action kernel writes per replica: never uniform
   int n_pair = 0, n_up = 0;
   std::vector<void*> allocs;
   void* stage = nullptr;
@@ -855,6 +915,15 @@ static int tabulate_pair_pod(pedn_sim* s) {
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemcpy(s->d_pair_pod, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(s, hipMemcpy(s->d_turn_tab, ttab.data(), ttab.size() * sizeof(double), hipMemcpyHostToDevice));
+  return PEDN_OK;
+}
+
+// rows[n_rows][R] (host) -> dst[n_rows][RS]
+template <typename T>
+static int push_matrix(pedn_sim* s, T* dst, const T* src, int n_rows) {
+  DevView& v = s->v;
+  if (n_rows == 0) return PEDN_OK;
+  HIP_TRY(s, hipMemcpy2D(dst, (size_t)v.RS * sizeof(T), src, (size_t)v.R * sizeof(T), (size_t)v.R * sizeof(T), n_rows, hipMemcpyHostToDevice));
   return PEDN_OK;
 }
 
@@ -1275,12 +1344,15 @@ static int launch_step(pedn_sim* s, int t) {
   const unsigned rgroups = (unsigned)(v.RS / 64);
   if (v.n_multi > 0) {
     size_t n = (size_t)v.n_multi * v.RS;
-    hipLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+    if (v.pr) hipLaunchKernelGGL(turn_prob_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+    else hipLaunchKernelGGL(turn_prob_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
   }
-  hipLaunchKernelGGL(node_kernel, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, v, t);
+  if (v.pr) hipLaunchKernelGGL(node_kernel<true>, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, v, t);
+  else hipLaunchKernelGGL(node_kernel<false>, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, v, t);
   if (v.n_pairs_corr > 0) {
-    size_t n = (size_t)v.n_pairs_corr * (v.RS / 2);
-    hipLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+    size_t n = (size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2);
+    if (v.pr) hipLaunchKernelGGL(link_kernel_pr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+    else hipLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
   }
   return PEDN_OK;
 }
@@ -1306,12 +1378,15 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   const unsigned rgroups = (unsigned)(v.RS / 64);
   if (v.n_multi > 0) {
     size_t n = (size_t)v.n_multi * v.RS;
-    hipExtLaunchKernelGGL(turn_prob_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
+    if (v.pr) hipExtLaunchKernelGGL(turn_prob_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
+    else hipExtLaunchKernelGGL(turn_prob_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
   }
-  hipExtLaunchKernelGGL(node_kernel, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
+  if (v.pr) hipExtLaunchKernelGGL(node_kernel<true>, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
+  else hipExtLaunchKernelGGL(node_kernel<false>, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
   if (v.n_pairs_corr > 0) {
-    size_t n = (size_t)v.n_pairs_corr * (v.RS / 2);
-    hipExtLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[4], ev[5], 0, v, t);
+    size_t n = (size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2);
+    if (v.pr) hipExtLaunchKernelGGL(link_kernel_pr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[4], ev[5], 0, v, t);
+    else hipExtLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[4], ev[5], 0, v, t);
   }
   HIP_TRY(s, hipGetLastError());
   HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -1401,6 +1476,86 @@ int pedn_timer_end(pedn_sim* s, float* ms) {
   HIP_TRY(s, hipEventRecord(s->ev1, s->stream));
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return PEDN_OK;
+}
+
+int pedn_set_link_params(pedn_sim* s, const double* kc, const double* kj, const double* vf, const int32_t* fft, const int32_t* tau_sw,
+                         const float* tt0) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  DevView& v = s->v;
+  if (!kc) {  // back to the shared parameters
+    v.pr = 0;
+    return PEDN_OK;
+  }
+  if (!kj || !vf || !fft || !tau_sw || !tt0) return fail(s, PEDN_E_ARG, "all six parameter matrices are required");
+  for (size_t i = 0; i < (size_t)v.L * v.R; ++i) {
+    if (!(kj[i] > kc[i]) || !(kc[i] > 0.0) || !(vf[i] > 0.0)) return fail(s, PEDN_E_ARG, "need 0 < k_critical < k_jam and free_flow_speed > 0");
+    if (fft[i] < 0 || tau_sw[i] < 0) return fail(s, PEDN_E_ARG, "negative look-back");
+  }
+  int rc;
+  const size_t n = (size_t)v.L * v.RS;
+  if (!s->d_kc_r) {
+    if ((rc = dalloc(s, n, &s->d_kc_r)) || (rc = dalloc(s, n, &s->d_kj_r)) || (rc = dalloc(s, n, &s->d_vf_r)) ||
+        (rc = dalloc(s, n, &s->d_fft_r)) || (rc = dalloc(s, n, &s->d_tausw_r)) || (rc = dalloc(s, n, &s->d_tt0_r))) return rc;
+    // padding lanes (replica >= R) must hold valid numbers too: start from a safe fill
+    std::vector<double> one(n, 1.0), two(n, 2.0);
+    HIP_TRY(s, hipMemcpy(s->d_kc_r, one.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(s, hipMemcpy(s->d_kj_r, two.data(), n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(s, hipMemcpy(s->d_vf_r, one.data(), n * 8, hipMemcpyHostToDevice));
+    std::vector<int32_t> big(n, 1 << 20);  // free_flow_tau far in the future: padding lanes stay idle
+    HIP_TRY(s, hipMemcpy(s->d_fft_r, big.data(), n * 4, hipMemcpyHostToDevice));
+    std::vector<int32_t> onei(n, 1);
+    HIP_TRY(s, hipMemcpy(s->d_tausw_r, onei.data(), n * 4, hipMemcpyHostToDevice));
+    std::vector<float> onef(n, 1.0f);
+    HIP_TRY(s, hipMemcpy(s->d_tt0_r, onef.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  if ((rc = push_matrix(s, s->d_kc_r, kc, v.L)) || (rc = push_matrix(s, s->d_kj_r, kj, v.L)) || (rc = push_matrix(s, s->d_vf_r, vf, v.L)) ||
+      (rc = push_matrix(s, s->d_fft_r, fft, v.L)) || (rc = push_matrix(s, s->d_tausw_r, tau_sw, v.L)) || (rc = push_matrix(s, s->d_tt0_r, tt0, v.L)))
+    return rc;
+  v.kc_r = s->d_kc_r; v.kj_r = s->d_kj_r; v.vf_r = s->d_vf_r; v.fft_r = s->d_fft_r; v.tausw_r = s->d_tausw_r; v.tt0_r = s->d_tt0_r;
+  v.pr = 1;
+  return PEDN_OK;
+}
+
+int pedn_set_od_weights_per_replica(pedn_sim* s, const double* w) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  DevView& v = s->v;
+  if (!w) {
+    v.pod_pr = 0;
+    return PEDN_OK;
+  }
+  const int np = s->n_pair, nt = s->n_turns, R = v.R;
+  if (np == 0) return PEDN_OK;
+  // P(od | up) per replica (path_finder.py:599-615), same arithmetic as tabulate_pair_pod, one column per replica
+  std::vector<double> pod((size_t)np * R), tab((size_t)std::max(nt, 1) * R, 0.0), upod(s->h_upod_od.size());
+  for (int r = 0; r < R; ++r) {
+    for (int u = 0; u < s->n_up; ++u) {
+      const int a = s->h_up_od_ptr[u], b = s->h_up_od_ptr[u + 1];
+      double tot = 0.0;
+      for (int q = a; q < b; ++q) tot += w[(size_t)s->h_upod_od[q] * R + r];
+      for (int q = a; q < b; ++q) upod[q] = tot > 0.0 ? w[(size_t)s->h_upod_od[q] * R + r] / tot : (b - a > 0 ? 1.0 / (double)(b - a) : 0.0);
+    }
+    for (int q = 0; q < np; ++q) pod[(size_t)q * R + r] = upod[s->h_pair_upod[q]];
+    for (int tn = 0; tn < nt; ++tn) {
+      if (!s->h_turn_mode[tn]) continue;
+      double acc = 0.0;
+      for (int q = s->h_turn_pair_ptr[tn]; q < s->h_turn_pair_ptr[tn + 1]; ++q) acc += 1.0 * pod[(size_t)q * R + r];
+      tab[(size_t)tn * R + r] = acc;
+    }
+  }
+  int rc;
+  if (!s->d_pair_pod_r) {
+    if ((rc = dalloc(s, (size_t)np * v.RS, &s->d_pair_pod_r)) || (rc = dalloc(s, (size_t)std::max(nt, 1) * v.RS, &s->d_turn_tab_r))) return rc;
+    HIP_TRY(s, hipMemset(s->d_pair_pod_r, 0, (size_t)np * v.RS * 8));
+    HIP_TRY(s, hipMemset(s->d_turn_tab_r, 0, (size_t)std::max(nt, 1) * v.RS * 8));
+  }
+  if ((rc = push_matrix(s, s->d_pair_pod_r, pod.data(), np)) || (rc = push_matrix(s, s->d_turn_tab_r, tab.data(), nt))) return rc;
+  v.pair_pod_r = s->d_pair_pod_r; v.turn_tab_r = s->d_turn_tab_r;
+  v.pod_pr = 1;
   return PEDN_OK;
 }
 

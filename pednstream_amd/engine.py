@@ -114,6 +114,8 @@ def _load():
         "pedn_timer_end": (C.c_int, [P, C.POINTER(C.c_float)]),
         "pedn_reset": (C.c_int, [P]),
         "pedn_profile_step": (C.c_int, [P, C.c_int32, C.POINTER(C.c_float)]),
+        "pedn_set_link_params": (C.c_int, [P, _F64P, _F64P, _F64P, _I32P, _I32P, _F32P]),
+        "pedn_set_od_weights_per_replica": (C.c_int, [P, _F64P]),
         "pedn_rl_configure": (C.c_int, [P, C.POINTER(RlDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "pedn_rl_apply_actions": (C.c_int, [P, C.c_void_p, C.c_int32]),
         "pedn_rl_observe": (C.c_int, [P, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -143,7 +145,8 @@ EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
            "pedn_device_ptr", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_rl_configure",
-           "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths"]
+           "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
+           "pedn_set_od_weights_per_replica"]
 
 
 class ModelError(RuntimeError):
@@ -226,6 +229,27 @@ class Engine:
         v = np.ascontiguousarray(values, dtype=np.float64)
         assert v.shape == (self.n_links, self.n_replicas)
         self._ck(self._lib.pedn_set_widths(self._h, int(which), v.ctypes.data_as(_F64P)))
+
+    def set_link_params(self, kc, kj, vf, fft, tau_sw, tt0):
+        """Per-replica k_critical / k_jam / free_flow_speed [n_links, n_replicas] + host-derived look-backs; None resets."""
+        if kc is None:
+            self._ck(self._lib.pedn_set_link_params(self._h, None, None, None, None, None, None))
+            return
+        arrs = [np.ascontiguousarray(a, dtype=dt) for a, dt in ((kc, np.float64), (kj, np.float64), (vf, np.float64),
+                                                                  (fft, np.int32), (tau_sw, np.int32), (tt0, np.float32))]
+        for a in arrs:
+            assert a.shape == (self.n_links, self.n_replicas), a.shape
+        self._ck(self._lib.pedn_set_link_params(self._h, arrs[0].ctypes.data_as(_F64P), arrs[1].ctypes.data_as(_F64P),
+                                                arrs[2].ctypes.data_as(_F64P), arrs[3].ctypes.data_as(_I32P),
+                                                arrs[4].ctypes.data_as(_I32P), arrs[5].ctypes.data_as(_F32P)))
+
+    def set_od_weights_per_replica(self, w):
+        if w is None:
+            self._ck(self._lib.pedn_set_od_weights_per_replica(self._h, None))
+            return
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        assert w.shape == (int(self.model["n_od"]), self.n_replicas), w.shape
+        self._ck(self._lib.pedn_set_od_weights_per_replica(self._h, w.ctypes.data_as(_F64P)))
 
     def get_widths(self, which):
         out = np.empty((self.n_links, self.n_replicas), dtype=np.float64)

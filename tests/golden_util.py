@@ -42,7 +42,15 @@ class Golden:
 def build_network(g: Golden, **kw):
     """This repository's Network for the golden's scenario, with the golden's demand arrays injected."""
     np.random.seed(g.info["np_seed"])
-    if g.info["scenario"] is not None:
+    if g.info.get("randomized"):
+        # the reference built this scenario with create_network(name, od_flows, link_params_overrides, demand_params_overrides)
+        rz = g.info["randomized"]
+        gen = NetworkEnvGenerator(DATA)
+        T = gen.create_network(g.info["scenario"], verbose=False).simulation_steps
+        od = {tuple(int(x) for x in k.split("_")): np.full(T + 1, w) for k, w in rz["od_flows"].items()}
+        net = gen.create_network(g.info["scenario"], od_flows=od, link_params_overrides=rz["link_params_overrides"],
+                                 demand_params_overrides=rz["demand_params_overrides"], verbose=False, **kw)
+    elif g.info["scenario"] is not None:
         net = NetworkEnvGenerator(DATA).create_network(g.info["scenario"], verbose=False, **kw)
     else:
         net = Network(np.array(g.info["adjacency"]), g.info["params"], origin_nodes=g.info["origin_nodes"],

@@ -1,0 +1,60 @@
+"""Per-replica scenarios on one topology (rank 2): replicas of ONE engine carry different link parameters, OD weights
+and demand; each replica must equal the reference run of its own scenario (goldens rand_*.npz, built by the reference's
+create_network with the overrides its own randomisers produced)."""
+import numpy as np
+import pytest
+
+import oracle_driver as od
+from golden_util import ALL_FIELDS, DATA, Golden, build_network, compare_fields
+from pednstream_amd import NetworkEnvGenerator
+from pednstream_amd.flatten import flatten_network
+from pednstream_amd.network import LINK_FIELDS
+from pednstream_amd.scenarios import ScenarioBatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,cases", [("nine_intersections", ["rand_nine_a", "rand_nine_b"]), ("delft", ["rand_delft_a", "rand_delft_b"])])
+def test_replicas_with_different_scenarios_match_their_reference_runs(name, cases):
+    goldens = [Golden(c) for c in cases]
+    R = len(goldens) + 1                                   # last replica keeps the base scenario
+    np.random.seed(goldens[0].info["np_seed"])
+    gen = NetworkEnvGenerator(DATA)
+    net = gen.create_network(name, verbose=False, n_replicas=R, rng_seed=0)
+    base_demand = {nid: np.array(n.demand, dtype=float) for nid, n in net.nodes.items() if n.demand is not None}
+    batch = ScenarioBatch(net, edge_distances=gen.network_data["edge_distances"])
+    T = net.simulation_steps
+    for r, g in enumerate(goldens):
+        rz = g.info["randomized"]
+        od_flows = {tuple(int(x) for x in k.split("_")): w for k, w in rz["od_flows"].items()}
+        batch.set_replica(r, link_params_overrides=rz["link_params_overrides"], od_flows=od_flows, demand=g.demand())
+    batch.commit()
+    steps = min(g.steps for g in goldens)
+    net.run(1, steps)
+    e = net._engine
+    rc, _ = e.error_flags()
+    assert rc == 0
+    for r, g in enumerate(goldens):
+        problems = compare_fields(lambda nm: e.read_block(LINK_FIELDS[nm][0], 0, steps, rep0=r, rep1=r + 1)[:, :, 0].T, g, e.n_links, steps)
+        assert not problems, f"replica {r} ({g.case}):\n" + "\n".join(problems)
+        tf = np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()])
+        assert np.array_equal(tf, g.z["tf_hist"][steps - 2]), f"turning fractions of replica {r}"
+    # the replica without overrides equals the CPU oracle of the base scenario
+    base = od.Oracle(flatten_network(net), seed=0, replica=R - 1)
+    for nid, d in base_demand.items():
+        base.set_demand(net.nodes[nid].index, d)
+    base.run(1, steps)
+    for nm in ALL_FIELDS:
+        mine = e.read_block(LINK_FIELDS[nm][0], 0, steps, rep0=R - 1, rep1=R)[:, :, 0].T
+        assert np.array_equal(mine[:e.n_links], base.field(nm)[:e.n_links, :steps]), nm
+    net.close()
+
+
+def test_scenario_batch_rejects_geometry_overrides_and_time_varying_weights():
+    net = NetworkEnvGenerator(DATA).create_network("nine_intersections", verbose=False, n_replicas=2)
+    batch = ScenarioBatch(net)
+    with pytest.raises(ValueError):
+        batch.set_replica(0, link_params_overrides={"0_1": {"length": 80}})
+    with pytest.raises(ValueError):
+        batch.set_replica(0, od_flows={(0, 8): np.arange(net.simulation_steps + 1.0)})
+    net.close()
