@@ -58,3 +58,21 @@ def test_scenario_batch_rejects_geometry_overrides_and_time_varying_weights():
     with pytest.raises(ValueError):
         batch.set_replica(0, od_flows={(0, 8): np.arange(net.simulation_steps + 1.0)})
     net.close()
+
+
+def test_vec_env_randomized_reset_gives_each_env_its_own_scenario():
+    """reset(options={'randomize': True}): every env gets its own link parameters, OD weights and demand."""
+    from pednstream_amd.rl_env import VecPedNetEnv
+    from pednstream_amd.scenarios import derive_statics
+
+    B, steps = 8, 60
+    np.random.seed(3)
+    env = VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", data_dir=DATA, seed=9)
+    obs0, _ = env.reset(options={"randomize": True}, seed=123)
+    sc = env.scenarios
+    assert len({tuple(sc.kc[:, r]) for r in range(B)}) > 1 and len({tuple(sc.od_w[:, r]) for r in range(B)}) == B
+    rng = np.random.default_rng(0)
+    for _ in range(steps):
+        obs, rew, term, trunc, _ = env.step(rng.uniform(0, 4, size=(B, env.n_actions)))
+    assert np.isfinite(obs).all() and len({obs[r].tobytes() for r in range(B)}) > 1
+    env.close()
