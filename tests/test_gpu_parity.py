@@ -262,3 +262,42 @@ def test_per_replica_widths_and_turning_fractions_via_replica_scope():
         with net.replica(r):
             assert np.array_equal(net.nodes[1].turning_fractions, custom_tf.get(r, base_tf))
     net.close()
+
+
+def test_fuzz_random_networks_engine_equals_oracle():
+    """40 random scenarios (random trees + chords, all three fundamental diagrams, separators, controllers, activity,
+    noise, odd time steps; the generator of the offline reference campaign oracle/fuzz_vs_reference.py): HIP engine and
+    CPU oracle agree bit for bit on every field, every replica, including the sticky error flags."""
+    import copy
+
+    from fuzz_cases import random_case
+    from pednstream_amd import Network
+
+    ran = 0
+    for seed in range(3000, 3040):
+        adj, params, origins, dests = random_case(seed)
+        np.random.seed(seed)
+        try:
+            net = Network(adj, copy.deepcopy(params), origin_nodes=origins, destination_nodes=dests, verbose=False, n_replicas=3,
+                          rng_seed=seed, replica_offset=seed % 5)
+        except KeyError:
+            continue                     # controller node on no OD path: the reference raises KeyError too
+        model = flatten_network(net)
+        T = params["simulation_steps"]
+        net.run(1, T, check=False)
+        e = net._engine
+        _, flags = e.error_flags()
+        for r in range(3):
+            o = od.Oracle(model, seed=seed, replica=seed % 5 + r)
+            o.run(1, T)
+            assert int(flags[r]) == o.flags(), (seed, r, int(flags[r]), o.flags())
+            if o.flags():
+                continue                 # after a raise site the reference stops; values past it are not defined
+            for fname in ALL_FIELDS:
+                mine = e.read_block(LINK_FIELDS[fname][0], 0, T, rep0=r, rep1=r + 1)[:, :, 0].T
+                assert np.array_equal(mine[:e.n_links], o.field(fname)[:e.n_links, :T]), (seed, r, fname)
+            tf = np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()])
+            assert np.array_equal(tf, o.tf()), (seed, r)
+            ran += 1
+        net.close()
+    assert ran >= 60
