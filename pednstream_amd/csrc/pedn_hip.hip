@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
 
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
 template <bool PR>
-__global__ __launch_bounds__(512, 8) void node_kernel(DevView v, int t) {
+__global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
   __shared__ double sPS[64 * 64];  // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
   __shared__ double sR[8 * 64];    // receiving flow of each wave's outgoing link
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
