@@ -52,14 +52,13 @@ static inline void rng_words(const rng_key* k, uint32_t call, uint32_t out[4]) {
   philox4x32_10(out, (uint32_t)k->seed, (uint32_t)(k->seed >> 32));
 }
 
+/* Irwin-Hall(8) over the eight 16-bit halves of ONE Philox call; 0x1.3988e1409212ep-16 = sqrt(1.5) * 2^-16 */
 static double rng_z(const rng_key* k) {
-  uint64_t s = 0;
   uint32_t w[4];
-  for (uint32_t c = 0; c < 3; ++c) {
-    rng_words(k, c, w);
-    s += (uint64_t)w[0] + w[1] + w[2] + w[3];
-  }
-  return (double)((int64_t)s - 6 * 4294967296LL) * 0x1p-32;
+  rng_words(k, 0, w);
+  uint32_t s = 0;
+  for (int i = 0; i < 4; ++i) s += (w[i] & 0xffffu) + (w[i] >> 16);
+  return (double)((int32_t)s - 262140) * 0x1.3988e1409212ep-16;
 }
 
 static int64_t rng_binomial(int64_t n, double p, const rng_key* k, int mode) {
@@ -67,12 +66,13 @@ static int64_t rng_binomial(int64_t n, double p, const rng_key* k, int mode) {
   if (mode == PEDN_RNG_MEANFIELD) return (int64_t)floor((double)n * p);
   if (p >= 1.0) return n;
   if (n <= 16) {
-    uint64_t thr = (uint64_t)floor(p * 4294967296.0);
+    uint32_t thr = (uint32_t)floor(p * 65536.0);
     uint32_t w[4];
     int64_t cnt = 0;
     for (int64_t i = 0; i < n; ++i) {
-      if ((i & 3) == 0) rng_words(k, (uint32_t)(i >> 2), w);
-      cnt += (uint64_t)w[i & 3] < thr;
+      if ((i & 7) == 0) rng_words(k, (uint32_t)(i >> 3), w);
+      uint32_t h = (w[(i >> 1) & 3] >> (16 * (i & 1))) & 0xffffu;
+      cnt += h < thr;
     }
     return cnt;
   }

@@ -14,11 +14,16 @@ Contract (all integer / IEEE-754 basic operations, no transcendental functions, 
 
   words(seed, replica, link, t, site)[i]  = Philox4x32-10(counter=(t, link, site | (i//4)<<8, replica),
                                                          key=(seed & 0xffffffff, seed >> 32))[i % 4]
-  z(...)        = (sum_{i<12} words[i] - 6*2^32) * 2^-32                # Irwin-Hall(12), exact in binary64
+  half(...)[i]  = (words[i//2] >> 16*(i%2)) & 0xffff                    # eight 16-bit uniforms per Philox call
+  z(...)        = (sum_{i<8} half[i] - 262140) * C,  C = 0x1.3988e1409212ep-16 = sqrt(1.5) * 2^-16
+                                                                        # Irwin-Hall(8) from ONE Philox call, exact in binary64
   normal(sigma) = sigma * z
   binomial(n,p) = 0 if n <= 0 or p <= 0;  n if p >= 1
-                  #{ i < n : words[i] < floor(p * 2^32) }               if n <= 16
+                  #{ i < n : half[i] < floor(p * 2^16) }                 if n <= 16   (one call for n <= 8, two otherwise)
                   clamp(floor(n*p + sqrt((n*p)*(1-p)) * z + 0.5), 0, n)  otherwise
+
+(Contract v2.  v1 summed twelve 32-bit words = three Philox calls per draw; on the GPU the 32x32->64 multiplies of Philox
+were the largest ALU cost of busy networks and of the speed-noise draw, so a draw now costs one call.)
 
 Sites: 0 = sending-flow release draw (link.py:337/343), 1 = activity draw (link.py:356),
        2 = receiving-flow reverse-pedestrian draw (link.py:382), 3 = speed noise (functions.py:133).
@@ -56,6 +61,10 @@ class Stream:
         self._buf = ()
         self._call = 0
 
+    def half(self, i):
+        w = self.word(i >> 1)
+        return (w >> (16 * (i & 1))) & 0xFFFF
+
     def word(self, i):
         call = i >> 2
         if call != self._call or not self._buf:
@@ -64,11 +73,14 @@ class Stream:
         return self._buf[i & 3]
 
 
+Z_SCALE = float.fromhex("0x1.3988e1409212ep-16")      # sqrt(1.5) * 2^-16: unit variance for the sum of 8 u16
+
+
 def z_irwin_hall(stream):
     s = 0
-    for i in range(12):
-        s += stream.word(i)
-    return float(s - 6 * 4294967296) * 2.0 ** -32
+    for i in range(8):
+        s += stream.half(i)
+    return float(s - 262140) * Z_SCALE
 
 
 def normal(sigma, stream):
@@ -85,8 +97,8 @@ def binomial(n, p, stream):
     if p >= 1.0:
         return n
     if n <= 16:
-        thr = int(math.floor(p * 4294967296.0))
-        return sum(1 for i in range(n) if stream.word(i) < thr)
+        thr = int(math.floor(p * 65536.0))
+        return sum(1 for i in range(n) if stream.half(i) < thr)
     mean = n * p
     sd = math.sqrt(mean * (1.0 - p))
     k = math.floor(mean + sd * z_irwin_hall(stream) + 0.5)

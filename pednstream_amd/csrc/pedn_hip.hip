@@ -162,7 +162,9 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
       const double* in = v.f64[F_IN];
       double i0 = in[at(wrap_idx(tp - tau, T1, fl), l, v.Lall, RS, r)], i1 = in[at(wrap_idx(tp - tau - 1, T1, fl), l, v.Lall, RS, r)];
       double i2 = in[at(wrap_idx(tp - tau - 2, T1, fl), l, v.Lall, RS, r)], i3 = in[at(wrap_idx(tp - tau - 3, T1, fl), l, v.Lall, RS, r)];
-      double d = (double)F * i0 + (double)(F * G) * i1 + (double)(F * pedn_powf(G, 2.0f)) * i2 + (double)(F * pedn_powf(G, 3.0f)) * i3;
+      float G2, G3;
+      pedn_powf_2_3(G, G2, G3);
+      double d = (double)F * i0 + (double)(F * G) * i1 + (double)(F * G2) * i2 + (double)(F * G3) * i3;
       d = ceil(d);
       if (d > 0.0) {  // link.py:326-330
         double mix = 0.8 * d + (1 - 0.8) * s;

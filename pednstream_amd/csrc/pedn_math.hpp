@@ -37,9 +37,8 @@ __device__ const uint64_t kExp2Tab[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
     0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
-// x >= 0 finite, y > 0 finite
-__device__ inline float pedn_powf(float x, float y) {
-  if (x == 0.0f) return 0.0f;
+// log2(x) in binary64 as glibc's powf computes it (log2_inline); x > 0 finite
+__device__ __forceinline__ double pedn_powf_log2(float x) {
   uint32_t ix = f2u(x);
   if (ix < 0x00800000u) {
     ix = f2u(x * 0x1p23f);
@@ -60,8 +59,11 @@ __device__ inline float pedn_powf(float x, float y) {
   double r4 = r2 * r2;
   double q = 0x1.71547652ab82bp0 * r + y0;
   q = p * r2 + q;
-  yy = yy * r4 + q;
-  double ylogx = (double)y * yy;
+  return yy * r4 + q;
+}
+
+// 2^(ylogx) rounded to binary32 as glibc's powf does (exp2_inline)
+__device__ __forceinline__ float pedn_powf_exp2(double ylogx) {
   if (ylogx <= -150.0) return 0.0f;
   double kd = ylogx + 0x1.8p+47;
   uint64_t ki = d2u(kd);
@@ -76,6 +78,20 @@ __device__ inline float pedn_powf(float x, float y) {
   e = zz * rr2 + e;
   e = e * s;
   return (float)e;
+}
+
+// x >= 0 finite, y > 0 finite
+__device__ inline float pedn_powf(float x, float y) {
+  if (x == 0.0f) return 0.0f;
+  return pedn_powf_exp2((double)y * pedn_powf_log2(x));
+}
+
+// x**2 and x**3 of the diffusion weights (link.py:211-212) share one logarithm
+__device__ inline void pedn_powf_2_3(float x, float& p2, float& p3) {
+  if (x == 0.0f) { p2 = p3 = 0.0f; return; }
+  const double lg = pedn_powf_log2(x);
+  p2 = pedn_powf_exp2(2.0 * lg);
+  p3 = pedn_powf_exp2(3.0 * lg);
 }
 
 // ---- exp ------------------------------------------------------------------------------------------------------
@@ -132,15 +148,12 @@ __device__ __forceinline__ void rng_words(const RngKey& k, uint32_t call, uint32
   philox4x32_10(w, k.k0, k.k1);
 }
 
+// Irwin-Hall(8) over the eight 16-bit halves of ONE Philox call; 0x1.3988e1409212ep-16 = sqrt(1.5) * 2^-16
 __device__ inline double rng_z(const RngKey& k) {
-  uint64_t s = 0;
   uint32_t w[4];
-#pragma unroll
-  for (uint32_t c = 0; c < 3; ++c) {
-    rng_words(k, c, w);
-    s += (uint64_t)w[0] + w[1] + w[2] + w[3];
-  }
-  return (double)((long long)s - 6ll * 4294967296ll) * 0x1p-32;
+  rng_words(k, 0u, w);
+  uint32_t s = (w[0] & 0xffffu) + (w[0] >> 16) + (w[1] & 0xffffu) + (w[1] >> 16) + (w[2] & 0xffffu) + (w[2] >> 16) + (w[3] & 0xffffu) + (w[3] >> 16);
+  return (double)((int)s - 262140) * 0x1.3988e1409212ep-16;
 }
 
 __device__ inline double rng_binomial(long long n, double p, const RngKey& k, int meanfield) {
@@ -148,13 +161,23 @@ __device__ inline double rng_binomial(long long n, double p, const RngKey& k, in
   if (meanfield) return floor((double)n * p);
   if (p >= 1.0) return (double)n;
   if (n <= 16) {
-    uint64_t thr = (uint64_t)floor(p * 4294967296.0);
+    const uint32_t thr = (uint32_t)floor(p * 65536.0);
+    const int nn = (int)n;
     uint32_t w[4];
+    rng_words(k, 0u, w);
     int cnt = 0;
-    for (int i = 0; i < (int)n; ++i) {
-      if ((i & 3) == 0) rng_words(k, (uint32_t)(i >> 2), w);
-      uint32_t wi = (i & 3) == 0 ? w[0] : (i & 3) == 1 ? w[1] : (i & 3) == 2 ? w[2] : w[3];
-      cnt += (uint64_t)wi < thr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t h = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+      cnt += (i < nn) && (h < thr);
+    }
+    if (nn > 8) {
+      rng_words(k, 1u, w);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t h = (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+        cnt += (i + 8 < nn) && (h < thr);
+      }
     }
     return (double)cnt;
   }
