@@ -638,7 +638,8 @@ __device__ __forceinline__ double clip_d(double x, double lo, double hi) { retur
 // ActionApplier (builders.py:281-352): one lane per (action slot, replica)
 __global__ void rl_apply_kernel(DevView v, RlView q) {
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int a = (int)(gid / (size_t)v.RS), r = (int)(gid % (size_t)v.RS);
+  const int a = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)v.RS));  // RS is a multiple of 128: uniform per wave
+  const int r = (int)(gid % (size_t)v.RS);
   if (a >= q.A || r >= v.R) return;
   const int ag = q.slot_agent[a], i = q.slot_idx[a];
   const int l = q.agent_links[q.agent_link_ptr[ag] + i];
@@ -661,66 +662,82 @@ __global__ void rl_apply_kernel(DevView v, RlView q) {
   }
 }
 
-// ObservationBuilder + _compute_rewards: one lane per (agent, replica)
-__global__ void rl_observe_kernel(DevView v, RlView q, int t, int accumulate) {
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int ag = (int)(gid / (size_t)v.RS), r = (int)(gid % (size_t)v.RS);
-  if (ag >= q.n_agents || r >= v.R) return;
+// ObservationBuilder + _compute_rewards.  Block = (agent, 64 replicas); wave w = the agent's w-th controlled link: its
+// features go straight to the observation row, its reward terms to LDS; wave 0 then folds them in the reference's order.
+__global__ __launch_bounds__(512) void rl_observe_kernel(DevView v, RlView q, int t, int accumulate) {
+  __shared__ float sT[PEDN_MAX_DEGREE][64], sD[PEDN_MAX_DEGREE][64], sKc[PEDN_MAX_DEGREE][64];
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const int r = (int)blockIdx.x * 64 + lane;
+  const int ag = (int)blockIdx.y;
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   const int la = q.agent_link_ptr[ag], n = q.agent_link_ptr[ag + 1] - la;
-  float* o = q.obs + (size_t)r * q.O + q.agent_obs_off[ag];
-  float reward = 0.0f;
-  bool rewarded = false;
-  if (q.agent_type[ag] == 0) {  // builders.py:87-117
-    const int f = q.agent_links[la], b = q.agent_links[la + 1];
-    float x[4] = {(float)v.f64[F_IN][at(t, f, Lall, RS, r)], (float)v.f64[F_OUT][at(t, f, Lall, RS, r)],
-                  (float)v.f64[F_IN][at(t, b, Lall, RS, r)], (float)v.f64[F_OUT][at(t, b, Lall, RS, r)]};
-    for (int k = 0; k < 4; ++k) {
-      if (q.normalize && (q.obs_mode == 1 || q.obs_mode == 2)) x[k] = x[k] / 20.0f;  // builders.py:183-188
-      o[k] = x[k];
+  const int type = q.agent_type[ag];
+  const bool live = r < v.R;
+  float* o = q.obs + (size_t)(live ? r : 0) * q.O + q.agent_obs_off[ag];
+  if (type == 0) {  // separator agent, builders.py:87-117
+    if (w == 0 && live) {
+      const int f = q.agent_links[la], b = q.agent_links[la + 1];
+      float x[4] = {(float)v.f64[F_IN][at(t, f, Lall, RS, r)], (float)v.f64[F_OUT][at(t, f, Lall, RS, r)],
+                    (float)v.f64[F_IN][at(t, b, Lall, RS, r)], (float)v.f64[F_OUT][at(t, b, Lall, RS, r)]};
+      for (int k = 0; k < 4; ++k) {
+        if (q.normalize && (q.obs_mode == 1 || q.obs_mode == 2)) x[k] = x[k] / 20.0f;  // builders.py:183-188
+        o[k] = x[k];
+      }
     }
-  } else {  // builders.py:119-177
-    float dens_sum = 0.0f, lr = 0.0f;
-    float dens_all[PEDN_MAX_DEGREE];
-    for (int i = 0; i < n; ++i) {
-      const int l = q.agent_links[la + i];
-      const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
-      const float in_l = (float)v.f64[F_IN][at(t, l, Lall, RS, r)], out_l = (float)v.f64[F_OUT][at(t, l, Lall, RS, r)];
-      const float in_r = (float)v.f64[F_IN][at(t, P.rev, Lall, RS, r)], out_r = (float)v.f64[F_OUT][at(t, P.rev, Lall, RS, r)];
-      const float dens = dens_at(v, P, l, t, r);
-      const float gate = (float)v.back[(size_t)l * RS + r];
-      float* oi = o + i * q.fpl;
+  } else if (w < n) {  // gater agent, link w: builders.py:119-177
+    const int l = q.agent_links[la + w];
+    const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
+    const float in_l = (float)v.f64[F_IN][at(t, l, Lall, RS, r)], out_l = (float)v.f64[F_OUT][at(t, l, Lall, RS, r)];
+    const float in_r = (float)v.f64[F_IN][at(t, P.rev, Lall, RS, r)], out_r = (float)v.f64[F_OUT][at(t, P.rev, Lall, RS, r)];
+    const float tt_l = v.f32[G_TT][at(t, l, L, RS, r)], tt_r = v.f32[G_TT][at(t, P.rev, L, RS, r)];
+    const float spd = q.obs_mode == 5 ? v.f32[G_V][at(t, l, L, RS, r)] : 0.0f;
+    const float dens = dens_at(v, P, l, t, r);
+    const float gate = (float)v.back[(size_t)l * RS + r];
+    if (live) {
+      float* oi = o + w * q.fpl;
       switch (q.obs_mode) {
         case 1: oi[0] = in_l; oi[1] = out_r; oi[2] = gate; break;
         case 2: oi[0] = in_l; oi[1] = out_r; oi[2] = dens; oi[3] = gate; break;
         case 3: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = gate; break;
         case 4: oi[0] = dens / (float)P.kj; oi[1] = gate; break;
-        default: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = v.f32[G_V][at(t, l, L, RS, r)]; oi[5] = dens; oi[6] = gate;
+        default: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = spd; oi[5] = dens; oi[6] = gate;
       }
       if (q.normalize) {  // builders.py:204-238, applied literally
         if (q.obs_mode == 1 || q.obs_mode == 2) { oi[0] = oi[0] / 20.0f; oi[1] = oi[1] / 20.0f; }
         else if (q.obs_mode == 3) { oi[0] = oi[0] / 6.0f; oi[1] = oi[1] / 20.0f; oi[2] = oi[2] / 20.0f; }
       }
-      // reward terms (pz_pednet_env.py:557-570), float32 throughout
-      const float tsum = v.f32[G_TT][at(t, l, L, RS, r)] + v.f32[G_TT][at(t, P.rev, L, RS, r)];
-      lr = (i == 0) ? 0.0f - tsum : lr - tsum;
-      if (dens > 4.0f) lr = lr - 10.0f * (dens - (float)P.kc);
-      if (i < PEDN_MAX_DEGREE) dens_all[i] = dens;
-      dens_sum = (i == 0) ? dens : dens_sum + dens;
     }
-    if (n > 1) {  // variance penalty, :572-577 (np.mean of float32: sequential float32 sum / n)
-      const float avg = dens_sum / (float)n;
-      float dsum = 0.0f;
-      for (int i = 0; i < n && i < PEDN_MAX_DEGREE; ++i) { float d = fabsf(dens_all[i] - avg); dsum = (i == 0) ? d : dsum + d; }
-      lr = lr - 10.0f * (dsum / (float)n);
-    }
-    reward = lr;
-    rewarded = true;
+    sT[w][lane] = tt_l + tt_r;  // T_ell + T_ell_reverse, float32 (pz_pednet_env.py:566)
+    sD[w][lane] = dens;
+    sKc[w][lane] = (float)P.kc;
   }
-  if (q.reward_mode == 0 && ag != 0) rewarded = false;  // the reference returns after the first agent (:581)
-  float* rw = q.rew + (size_t)r * q.n_agents + ag;
-  const float add = rewarded ? reward : 0.0f;
-  *rw = (accumulate && rewarded) ? *rw + add : (accumulate ? *rw : add);
+  __syncthreads();
+  if (w == 0 && live) {
+    float reward = 0.0f;
+    bool rewarded = false;
+    if (type == 1) {  // reward terms in link order, float32 throughout (pz_pednet_env.py:557-577)
+      float lr = 0.0f, dens_sum = 0.0f;
+      for (int i = 0; i < n; ++i) {
+        const float d = sD[i][lane];
+        lr = (i == 0) ? 0.0f - sT[i][lane] : lr - sT[i][lane];
+        if (d > 4.0f) lr = lr - 10.0f * (d - sKc[i][lane]);
+        dens_sum = (i == 0) ? d : dens_sum + d;
+      }
+      if (n > 1) {  // np.mean of float32: sequential float32 sum / n
+        const float avg = dens_sum / (float)n;
+        float dsum = 0.0f;
+        for (int i = 0; i < n; ++i) { const float d = fabsf(sD[i][lane] - avg); dsum = (i == 0) ? d : dsum + d; }
+        lr = lr - 10.0f * (dsum / (float)n);
+      }
+      reward = lr;
+      rewarded = true;
+    }
+    if (q.reward_mode == 0 && ag != 0) rewarded = false;  // the reference returns after the first agent (:581)
+    float* rw = q.rew + (size_t)r * q.n_agents + ag;
+    const float add = rewarded ? reward : 0.0f;
+    *rw = (accumulate && rewarded) ? *rw + add : (accumulate ? *rw : add);
+  }
 }
 
 // ---- state initialisation / host <-> device helpers ---------------------------------------------------------
@@ -1653,8 +1670,7 @@ int pedn_rl_observe(pedn_sim* s, int32_t t, int32_t accumulate, float* obs, floa
   HIP_TRY(s, hipSetDevice(s->device));
   DevView& v = s->v;
   RlView& q = s->rl;
-  size_t n = (size_t)q.n_agents * v.RS;
-  hipLaunchKernelGGL(rl_observe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, q, t, accumulate);
+  hipLaunchKernelGGL(rl_observe_kernel, dim3((unsigned)(v.RS / 64), (unsigned)q.n_agents), dim3(512), 0, s->stream, v, q, t, accumulate);
   HIP_TRY(s, hipGetLastError());
   if (obs) HIP_TRY(s, hipMemcpyAsync(obs, q.obs, (size_t)v.R * q.O * sizeof(float), hipMemcpyDeviceToHost, s->stream));
   if (rewards) HIP_TRY(s, hipMemcpyAsync(rewards, q.rew, (size_t)v.R * q.n_agents * sizeof(float), hipMemcpyDeviceToHost, s->stream));
