@@ -32,7 +32,10 @@ def counters(d):
     rows = list(csv.DictReader(open(one(os.path.join(d, "*", "*_counter_collection.csv")))))
     by = {}
     for r in rows:
-        by.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].split("(")[0].split("<")[0]       # "void node_kernel<false>(DevView, int)" -> "node_kernel"
+        if name.startswith("void "):
+            name = name[5:]
+        by.setdefault(name, []).append(float(r["Counter_Value"]))
     return by
 
 
