@@ -135,7 +135,9 @@ def test_config2_nine_intersections_256_replicas_vs_oracle_and_goldens():
     net.close()
 
 
-@pytest.mark.parametrize("name,replicas,steps", [("delft", 64, 60), ("melbourne", 128, 120), ("45_intersections", 64, 200)])
+@pytest.mark.parametrize("name,replicas,steps", [("delft", 64, 60), ("melbourne", 128, 120), ("45_intersections", 64, 200),
+                                                 ("delft", 192, 500), ("melbourne", 256, 500), ("45_intersections", 128, 700),
+                                                 ("nine_intersections", 64, 500), ("small_network", 64, 500)])
 def test_engine_equals_oracle_on_large_networks(name, replicas, steps):
     """Same seeded inputs through the HIP path and the CPU oracle; sampled replicas, all fields bit-exact."""
     from pednstream_amd import NetworkEnvGenerator
