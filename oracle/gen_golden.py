@@ -124,6 +124,20 @@ def randomized_case(case, name, rand_seed, steps=None, replica=0, np_seed=202610
                                                                        "demand_params_overrides": plain(dem_ov)}})
 
 
+def randnet_case(case, name, rand_seed, steps=None, replica=0, np_seed=20261003):
+    """The reference's full randomize_network(name, seed) (env_loader.py:160-181): perturbed OD NODES (topology of the
+    virtual links changes), link parameters, OD weights and demand parameters, then create_network."""
+    ref = rh.load_reference()
+    np.random.seed(np_seed)
+    gen = ref["env"].NetworkEnvGenerator()
+    gen.create_network(name)
+    net = gen.randomize_network(name, seed=rand_seed)
+    net, static, state, extras = rh.run_reference(None, steps=steps, seed=0, replica=replica, record_tf=True, network=net)
+    extras["tf"] = tf_matrix(net, extras)
+    save(case, static, state, extras, {"scenario": name, "seed": 0, "replica": replica, "mode": "philox", "np_seed": np_seed,
+                                       "mutations": [], "randomize_network_seed": rand_seed})
+
+
 def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_steps=150, seed=0, replica=0,
             np_seed=20261003, action_seed=1):
     """Config #5 caller: the reference's ActionApplier / ObservationBuilder / reward (rl/builders.py,
@@ -318,6 +332,9 @@ CASES.update({
     "output_six_node": lambda: output_case("output_six_node", "od_flow_example",
                                            mutations=[(t, "back_gate_delta", 3, 5, -0.1) for t in range(100, 109)]),
     "output_corridor": lambda: output_case("output_corridor", "long_corridor", mutations=[(150, "separator_set", 2, 3, 1.25)]),
+    "randnet_i45_a": lambda: randnet_case("randnet_i45_a", "45_intersections", 3, steps=150),
+    "randnet_i45_b": lambda: randnet_case("randnet_i45_b", "45_intersections", 8, steps=150, replica=2),
+    "randnet_nine": lambda: randnet_case("randnet_nine", "nine_intersections", 5, steps=200, replica=1),
     "rand_nine_a": lambda: randomized_case("rand_nine_a", "nine_intersections", 11, steps=220, replica=0),
     "rand_nine_b": lambda: randomized_case("rand_nine_b", "nine_intersections", 12, steps=220, replica=1),
     "rand_delft_a": lambda: randomized_case("rand_delft_a", "delft", 21, steps=60, replica=0),

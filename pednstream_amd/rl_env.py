@@ -256,3 +256,63 @@ class PedNetParallelEnv:
 
     def close(self):
         self._vec.close()
+
+
+class MultiScenarioVecEnv:
+    """Vectorised env whose groups of ``group_size`` envs each live in their OWN randomised scenario, topology included.
+
+    ``NetworkEnvGenerator.randomize_network`` (src/utils/env_loader.py:160-181) also moves origin / destination nodes,
+    which changes which nodes own virtual links and therefore the node classes and routes: such scenarios cannot share
+    one engine.  Here every group is a separate ``Network`` + engine (own HIP stream, same GPU) built by the mirrored
+    ``randomize_network``; inside a group the envs share the scenario and differ by RNG key.  Agents are defined by the
+    scenario's ``controllers`` section, which the randomiser never touches, so action / observation layouts agree."""
+
+    def __init__(self, dataset, n_envs, group_size=64, obs_mode="option1", normalize_obs=False, action_gap=1, seed=0,
+                 reward_mode="reference", data_dir="data", device=0):
+        from .env_loader import NetworkEnvGenerator
+
+        self.dataset, self.n_envs, self.group_size = dataset, int(n_envs), int(group_size)
+        self.kw = dict(obs_mode=obs_mode, normalize_obs=normalize_obs, action_gap=action_gap, reward_mode=reward_mode,
+                       data_dir=data_dir)
+        self.seed, self.device, self.data_dir = int(seed), device, data_dir
+        self.sizes = [min(self.group_size, self.n_envs - o) for o in range(0, self.n_envs, self.group_size)]
+        self.generators = [NetworkEnvGenerator(data_dir) for _ in self.sizes]
+        self.groups = []
+        off = 0
+        for gen, size in zip(self.generators, self.sizes):
+            net = gen.create_network(dataset, verbose=False, n_replicas=size, replica_offset=off, rng_seed=self.seed, device=device)
+            self.groups.append(VecPedNetEnv(dataset, n_envs=size, network=net, **self.kw))
+            off += size
+        g0 = self.groups[0]
+        self.possible_agents, self.n_actions, self.n_obs = g0.possible_agents, g0.n_actions, g0.n_obs
+        self.action_low, self.action_high = g0.action_low, g0.action_high
+        self.simulation_steps = g0.simulation_steps
+
+    def reset(self, options=None, seed=None):
+        randomize = bool(options and options.get("randomize", False))
+        obs = []
+        off = 0
+        for k, (gen, size) in enumerate(zip(self.generators, self.sizes)):
+            if randomize:
+                self.groups[k].close()
+                net = gen.randomize_network(self.dataset, seed=None if seed is None else seed + k, verbose=False, n_replicas=size,
+                                            replica_offset=off, rng_seed=self.seed, device=self.device)
+                self.groups[k] = VecPedNetEnv(self.dataset, n_envs=size, network=net, **self.kw)
+                if self.groups[k].possible_agents != self.possible_agents:
+                    raise RuntimeError("randomisation changed the agent set")
+            o, _ = self.groups[k].reset()
+            obs.append(o)
+            off += size
+        return np.concatenate(obs, axis=0), {}
+
+    def step(self, actions):
+        actions = np.asarray(actions, dtype=np.float64)
+        outs, off = [], 0
+        for g, size in zip(self.groups, self.sizes):
+            outs.append(g.step(actions[off:off + size]))
+            off += size
+        return (np.concatenate([o[0] for o in outs], axis=0), np.concatenate([o[1] for o in outs], axis=0), outs[0][2], False, {})
+
+    def close(self):
+        for g in self.groups:
+            g.close()

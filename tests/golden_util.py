@@ -42,7 +42,12 @@ class Golden:
 def build_network(g: Golden, **kw):
     """This repository's Network for the golden's scenario, with the golden's demand arrays injected."""
     np.random.seed(g.info["np_seed"])
-    if g.info.get("randomized"):
+    if g.info.get("randomize_network_seed") is not None:
+        # the reference called create_network(name) and then randomize_network(name, seed) on the same generator
+        gen = NetworkEnvGenerator(DATA)
+        gen.create_network(g.info["scenario"], verbose=False)
+        net = gen.randomize_network(g.info["scenario"], seed=g.info["randomize_network_seed"], verbose=False, **kw)
+    elif g.info.get("randomized"):
         # the reference built this scenario with create_network(name, od_flows, link_params_overrides, demand_params_overrides)
         rz = g.info["randomized"]
         gen = NetworkEnvGenerator(DATA)

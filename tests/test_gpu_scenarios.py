@@ -76,3 +76,26 @@ def test_vec_env_randomized_reset_gives_each_env_its_own_scenario():
         obs, rew, term, trunc, _ = env.step(rng.uniform(0, 4, size=(B, env.n_actions)))
     assert np.isfinite(obs).all() and len({obs[r].tobytes() for r in range(B)}) > 1
     env.close()
+
+
+def test_multi_scenario_env_groups_have_their_own_topology():
+    """randomize_network also moves OD nodes: every group is its own engine.  Group 0 under seed 3 is the scenario of golden
+    randnet_i45_a (reference randomize_network('45_intersections', seed=3)); stepping with the widths untouched must
+    reproduce that reference run for the env whose RNG key is 0."""
+    from pednstream_amd.rl_env import MultiScenarioVecEnv
+
+    g = Golden("randnet_i45_a")
+    env = MultiScenarioVecEnv("45_intersections", n_envs=5, group_size=2, obs_mode="option3", data_dir=DATA, seed=0)
+    env.reset(options={"randomize": True}, seed=3)
+    nets = [grp.network for grp in env.groups]
+    assert len(nets) == 3 and [n.n_replicas for n in nets] == [2, 2, 1]
+    assert nets[0].origin_nodes == g.meta["origin_nodes"] and nets[0].destination_nodes == g.meta["destination_nodes"]
+    assert len({(tuple(n.origin_nodes), tuple(n.destination_nodes), tuple(l.k_critical for l in n._link_list)) for n in nets}) > 1
+    steps = 80
+    for _ in range(steps):         # t = 1..steps: sending/receiving flows are then defined up to index steps-1
+        obs, rew, term, trunc, _ = env.step(np.tile(env.action_high, (5, 1)))      # gates fully open = unchanged widths
+    assert obs.shape == (5, env.n_obs) and np.isfinite(obs).all()
+    e = nets[0]._engine
+    problems = compare_fields(lambda nm: e.read_block(LINK_FIELDS[nm][0], 0, steps, rep0=0, rep1=1)[:, :, 0].T, g, e.n_links, steps)
+    assert not problems, "\n".join(problems)
+    env.close()
