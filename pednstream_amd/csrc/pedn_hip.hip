@@ -337,21 +337,23 @@ __global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
       uint32_t flw = 0;
       const int tm1 = wrap_idx(tp - 1, v.T1, flw);
       fl |= flw;
-      // ---- one batch of independent loads (see SlotIn)
+      // ---- one batch of independent loads (see SlotIn): straight-line and unconditional so that the compiler issues them
+      // back to back (a load skipped by a branch costs a wait at the join); the few values of an `early` step are unused
       SlotIn x;
+      const int t_sw = tp + 1 - Pout.tau_sw > 0 ? tp + 1 - Pout.tau_sw : 0;
       x.n_in = v.f32[G_N][at(tp, lin, L, RS, r)];
-      x.n_out = early ? 0.0f : v.f32[G_N][at(tp, lout, L, RS, r)];
-      x.k_in = early ? 0.0f : v.f32[G_K][at(tp, lin, L, RS, r)];
-      x.att_in = early ? 0.0f : v.f32[G_ATT][at(tp, lin, L, RS, r)];
+      x.n_out = v.f32[G_N][at(tp, lout, L, RS, r)];
+      x.k_in = v.f32[G_K][at(tp, lin, L, RS, r)];
+      x.att_in = v.f32[G_ATT][at(tp, lin, L, RS, r)];
       x.co_in = v.f64[F_CO][at(tp, lin, Lall, RS, r)];
-      x.s_prev = early ? 0.0 : v.f64[F_S][at(tm1, lin, L, RS, r)];
-      const double fu = v.front_u[lin], bu = v.back_u[lout];
-      x.front_in = early ? 0.0 : (fu == fu ? fu : v.front[(size_t)lin * RS + r]);
-      x.sepw_in = (!early && Pin.sep) ? v.sepw[(size_t)lin * RS + r] : 0.0;
-      x.co_sw = (tp + 1 - Pout.tau_sw >= 0) ? v.f64[F_CO][at(tp + 1 - Pout.tau_sw, lout, Lall, RS, r)] : 0.0;
+      x.s_prev = v.f64[F_S][at(tm1, lin, L, RS, r)];
+      x.co_sw = v.f64[F_CO][at(t_sw, lout, Lall, RS, r)];
       x.ci_out = v.f64[F_CI][at(tp, lout, Lall, RS, r)];
       x.r_prev = v.f64[F_R][at(tm1, lout, L, RS, r)];
+      const double fu = v.front_u[lin], bu = v.back_u[lout];
+      x.front_in = fu == fu ? fu : v.front[(size_t)lin * RS + r];
       x.back_out = bu == bu ? bu : v.back[(size_t)lout * RS + r];
+      x.sepw_in = Pin.sep ? v.sepw[(size_t)lin * RS + r] : 0.0;
       x.sepw_out = Pout.sep ? v.sepw[(size_t)lout * RS + r] : 0.0;
       if (static_tf) {
         const bool shared = v.tf_u[turn0] == v.tf_u[turn0];  // not NaN
