@@ -208,6 +208,8 @@ class Engine:
     def set_turning_fractions(self, node_index, tf, replica=None):
         tf = np.asarray(tf, dtype=np.float64)
         if tf.ndim == 2:       # [edge_num, R] host mirror: NaN rows mean "not imposed"
+            if not np.isnan(tf).any() and (tf == tf[:, :1]).all():
+                return self.set_turning_fractions(node_index, tf[:, 0], None)     # same for every replica: keeps the scalar fast path
             for r in range(tf.shape[1]):
                 if not np.isnan(tf[:, r]).any():
                     self.set_turning_fractions(node_index, tf[:, r], r)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle_driver as od
-from golden_util import ALL_FIELDS, F64_FIELDS, Golden, apply_mutation, build_network, compare_fields
+from golden_util import ALL_FIELDS, Golden, apply_mutation, build_network, compare_fields
 from pednstream_amd import engine as eng
 from pednstream_amd.flatten import flatten_network
 from pednstream_amd.network import LINK_FIELDS

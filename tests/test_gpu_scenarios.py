@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_driver as od
-from golden_util import ALL_FIELDS, DATA, Golden, build_network, compare_fields
+from golden_util import ALL_FIELDS, DATA, Golden, compare_fields
 from pednstream_amd import NetworkEnvGenerator
 from pednstream_amd.flatten import flatten_network
 from pednstream_amd.network import LINK_FIELDS
@@ -63,7 +63,6 @@ def test_scenario_batch_rejects_geometry_overrides_and_time_varying_weights():
 def test_vec_env_randomized_reset_gives_each_env_its_own_scenario():
     """reset(options={'randomize': True}): every env gets its own link parameters, OD weights and demand."""
     from pednstream_amd.rl_env import VecPedNetEnv
-    from pednstream_amd.scenarios import derive_statics
 
     B, steps = 8, 60
     np.random.seed(3)

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from golden_util import ALL_FIELDS, Golden, compare_fields, run_oracle
+from golden_util import Golden, compare_fields, run_oracle
 
 CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full", "i45_prefix", "delft_prefix",
          "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky", "nine_replica0", "nine_replica1",

@@ -4,7 +4,6 @@ import json
 import zlib
 from types import SimpleNamespace
 
-import numpy as np
 import pytest
 
 from golden_util import Golden, build_network, run_oracle
