@@ -23,6 +23,36 @@ OBS_MODES = {"option1": 1, "option2": 2, "option3": 3, "option4": 4, "option5": 
 FEATURES_PER_LINK = {"option1": 3, "option2": 4, "option3": 5, "option4": 2, "option5": 7}
 
 
+class Box:
+    """Minimal stand-in for ``gymnasium.spaces.Box`` (low / high / shape / dtype / sample / contains); the real class is
+    returned instead when gymnasium is installed (rl/spaces.py:41-105 builds the same bounds)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low = np.broadcast_to(np.asarray(low, dtype=dtype), shape).copy()
+        self.high = np.broadcast_to(np.asarray(high, dtype=dtype), shape).copy()
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+
+    def sample(self, rng=None):
+        rng = rng or np.random.default_rng()
+        lo = np.where(np.isfinite(self.low), self.low, -1e6)
+        hi = np.where(np.isfinite(self.high), self.high, 1e6)
+        return rng.uniform(lo, hi).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+def _make_box(low, high, shape):
+    try:
+        from gymnasium import spaces
+
+        return spaces.Box(low=np.broadcast_to(np.asarray(low, dtype=np.float32), shape).copy(),
+                          high=np.broadcast_to(np.asarray(high, dtype=np.float32), shape).copy(), shape=shape, dtype=np.float32)
+    except Exception:
+        return Box(low, high, shape)
+
+
 class AgentManager:
     """Maps the scenario's ``controllers`` section to agents (rl/discovery.py)."""
 
@@ -222,6 +252,20 @@ class PedNetParallelEnv:
     @property
     def sim_step(self):
         return self._vec.sim_step
+
+    def action_space(self, agent):
+        """Physical width bounds (rl/spaces.py:41-73): [min_sep, width - min_sep] for a separator, [0, link width] per
+        controlled link for a gater."""
+        if agent not in self._vec.action_slices:
+            raise ValueError(f"Agent {agent} not found in action spaces")
+        sl = self._vec.action_slices[agent]
+        return _make_box(self._vec.action_low[sl], self._vec.action_high[sl], (sl.stop - sl.start,))
+
+    def observation_space(self, agent):
+        if agent not in self._vec.obs_slices:
+            raise ValueError(f"Agent {agent} not found in observation spaces")
+        sl = self._vec.obs_slices[agent]
+        return _make_box(-np.inf, np.inf, (sl.stop - sl.start,))
 
     def _dict(self, row):
         return {a: np.array(row[sl]) for a, sl in self._vec.obs_slices.items()}

@@ -75,6 +75,10 @@ def test_single_env_facade_and_reset():
         return out
 
     obs0, _ = env.reset()
+    for a in env.possible_agents:
+        sp, ob = env.action_space(a), env.observation_space(a)
+        assert sp.shape == (len(env.agent_manager.get_gater_outgoing_links(a)),) and (sp.low == 0).all() and (sp.high == 4).all()
+        assert ob.shape == obs0[a].shape and sp.contains(sp.sample())
     assert all((v == np.float32([0, 0, 0, 0, 4] * (len(v) // 5))).all() for v in obs0.values())   # initial obs [0,0,0,0,width]
     first = run(30)
     env.reset()
