@@ -138,6 +138,32 @@ def randnet_case(case, name, rand_seed, steps=None, replica=0, np_seed=20261003)
                                        "mutations": [], "randomize_network_seed": rand_seed})
 
 
+def native_ensemble(case, name, n_runs=64, times=(100, 200, 300, 400, 498)):
+    """G6: the reference under its OWN numpy RNG, many seeds -> per-run densities / cumulative inflows at a few
+    times plus each run's demand.  Used to check that the injected RNG contract (different stream, approximate binomial and
+    normal transforms) reproduces the reference's ensemble statistics, not just itself."""
+    ref = rh.load_reference()
+    dens, cin, demands = [], [], {}
+    for k in range(n_runs):
+        np.random.seed(5000 + k)
+        net = ref["env"].NetworkEnvGenerator().create_network(name)
+        for t in range(1, net.simulation_steps):
+            net.network_loading(t)
+        links = list(net.links.values())
+        dens.append(np.array([[l.density[t] for t in times] for l in links], dtype=np.float32))
+        cin.append(np.array([[l.cumulative_inflow[t] for t in times] for l in links], dtype=np.float64))
+        for nid, node in net.nodes.items():
+            if node.demand is not None:
+                demands.setdefault(int(nid), []).append(np.asarray(node.demand, dtype=np.float64))
+    out = {"times": np.array(times), "density": np.array(dens), "cumulative_inflow": np.array(cin),
+           "info_json": np.array(json.dumps({"scenario": name, "n_runs": n_runs, "numpy": np.__version__}))}
+    for nid, arrs in demands.items():
+        out[f"demand_{nid}"] = np.array(arrs)
+    path = os.path.join(OUT, case + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{case}: {os.path.getsize(path) / 1024:.0f} KiB ({n_runs} native-RNG runs)")
+
+
 def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_steps=150, seed=0, replica=0,
             np_seed=20261003, action_seed=1):
     """Config #5 caller: the reference's ActionApplier / ObservationBuilder / reward (rl/builders.py,
@@ -332,6 +358,7 @@ CASES.update({
     "output_six_node": lambda: output_case("output_six_node", "od_flow_example",
                                            mutations=[(t, "back_gate_delta", 3, 5, -0.1) for t in range(100, 109)]),
     "output_corridor": lambda: output_case("output_corridor", "long_corridor", mutations=[(150, "separator_set", 2, 3, 1.25)]),
+    "g6_nine_native": lambda: native_ensemble("g6_nine_native", "nine_intersections"),
     "randnet_i45_a": lambda: randnet_case("randnet_i45_a", "45_intersections", 3, steps=150),
     "randnet_i45_b": lambda: randnet_case("randnet_i45_b", "45_intersections", 8, steps=150, replica=2),
     "randnet_nine": lambda: randnet_case("randnet_nine", "nine_intersections", 5, steps=200, replica=1),

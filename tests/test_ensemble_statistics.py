@@ -1,0 +1,45 @@
+"""Distributional parity: the injected RNG contract uses its own stream and approximate binomial / normal
+transforms, so besides bit-exact parity under the shared contract the ENSEMBLE statistics must match the reference run
+under numpy's native RNG.  tests/golden/g6_nine_native.npz holds 64 native-RNG reference runs of nine_intersections
+(per-run demand included); the oracle runs the same 64 demands with 64 RNG keys."""
+import numpy as np
+
+import oracle_driver as od
+from golden_util import DATA, GOLDEN
+from pednstream_amd import NetworkEnvGenerator
+from pednstream_amd.flatten import flatten_network
+
+
+def test_contract_rng_reproduces_native_rng_ensemble_statistics():
+    z = np.load(f"{GOLDEN}/g6_nine_native.npz")
+    times = z["times"]
+    ref_k, ref_c = z["density"].astype(np.float64), z["cumulative_inflow"]       # [runs, links, times]
+    R = ref_k.shape[0]
+    np.random.seed(0)
+    net = NetworkEnvGenerator(DATA).create_network("nine_intersections", verbose=False)
+    model = flatten_network(net)
+    L = model["n_links"]
+    mine_k, mine_c = np.empty_like(ref_k), np.empty_like(ref_c)
+    origins = [int(k[len("demand_"):]) for k in z.files if k.startswith("demand_")]
+    for r in range(R):
+        o = od.Oracle(model, seed=424242, replica=r)
+        for nid in origins:
+            o.set_demand(net.nodes[nid].index, z[f"demand_{nid}"][r])
+        o.run(1, net.simulation_steps)
+        assert o.flags() == 0
+        mine_k[r] = o.field("density")[:L, times]
+        mine_c[r] = o.field("cumulative_inflow")[:L, times]
+        o.close()
+    for name, a, b, floor in (("density", ref_k, mine_k, 0.03), ("cumulative_inflow", ref_c, mine_c, 3.0)):
+        diff = np.abs(a.mean(axis=0) - b.mean(axis=0))
+        se = np.sqrt((a.var(axis=0) + b.var(axis=0)) / R)
+        ok = diff <= 4.5 * se + floor
+        assert ok.mean() >= 0.97, f"{name}: only {ok.mean():.3f} of the (link, time) means agree within sampling error"
+        # spread of the ensembles agrees as well (ratio of standard deviations, where there is any spread)
+        sa, sb = a.std(axis=0), b.std(axis=0)
+        m = (sa > 10 * floor / 3) & (sb > 10 * floor / 3)
+        if m.any():
+            ratio = sb[m] / sa[m]
+            assert 0.6 < np.median(ratio) < 1.6, (name, np.median(ratio))
+    total_ref, total_mine = ref_c[:, :, -1].sum(axis=1).mean(), mine_c[:, :, -1].sum(axis=1).mean()
+    assert abs(total_mine - total_ref) <= 0.02 * total_ref, (total_ref, total_mine)
