@@ -307,6 +307,22 @@ SEP_PARAMS = {
 }
 
 
+# Edge cases: moving-average window longer than the horizon (W = 100/dt = 50 > T = 40), and a network nobody enters.
+EDGE_ADJ = [[0, 1, 0, 0], [1, 0, 1, 1], [0, 1, 0, 1], [0, 1, 1, 0]]
+EDGE_PARAMS_SHORT = {
+    "unit_time": 2, "simulation_steps": 40, "assign_flows_type": "classic", "seed": 9,
+    "path_finder": {"k_paths": 2, "temp": 5, "alpha": 1, "beta": 0.5, "omega": 0.8},
+    "default_link": {"length": 12, "width": 2.5, "free_flow_speed": 1.4, "k_critical": 2, "k_jam": 6, "gamma": 0.01,
+                     "speed_noise_std": 0.05, "fd_type": "yperman", "bi_factor": 1, "activity_probability": 0.2},
+    "demand": {"origin_0": {"peak_lambda": 6, "base_lambda": 4}},
+}
+EDGE_PARAMS_EMPTY = {
+    "unit_time": 10, "simulation_steps": 120, "assign_flows_type": "classic", "seed": 9,
+    "default_link": {"length": 50, "width": 2, "free_flow_speed": 1.1, "k_critical": 2, "k_jam": 6, "gamma": 0.01,
+                     "speed_noise_std": 0.05, "fd_type": "greenshields"},
+    "demand": {"origin_0": {"pattern": "constant", "base_lambda": 0}},
+}
+
 # A hub with 7 neighbours that is also an origin: 8 slots, the largest node the kernels support (PEDN_MAX_DEGREE).
 STAR_N = 15
 STAR_ADJ = [[0] * STAR_N for _ in range(STAR_N)]
@@ -348,6 +364,8 @@ CASES = {
     "forky": lambda: direct_case("forky", FORKY_ADJ, FORKY_PARAMS, [0, 4], tf_nodes=[1],
                                  tf_values=[[1, 0, 0.5, 0.5, 0, 1]],
                                  mutations=[(40, "back_gate_set", 1, 2, 0.0), (120, "back_gate_set", 1, 2, 1.0)]),
+    "edge_window_gt_T": lambda: direct_case("edge_window_gt_T", EDGE_ADJ, EDGE_PARAMS_SHORT, [0], destination_nodes=[2, 3], seed=4, replica=1),
+    "edge_empty": lambda: direct_case("edge_empty", EDGE_ADJ, EDGE_PARAMS_EMPTY, [0], seed=4, replica=0),
     "star8": lambda: direct_case("star8", STAR_ADJ, STAR_PARAMS, [0, 8, 12], destination_nodes=[9, 10, 11, 13, 14, 0], seed=21, replica=2),
     "odd_params": lambda: direct_case("odd_params", ODD_ADJ, ODD_PARAMS, [0, 6], destination_nodes=[6, 0], seed=11, replica=5),
     "odd_separators": lambda: direct_case("odd_separators", SEP_ADJ, SEP_PARAMS, [0, 4], seed=2, replica=9,

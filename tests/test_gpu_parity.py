@@ -14,7 +14,7 @@ from pednstream_amd.network import LINK_FIELDS
 pytestmark = pytest.mark.gpu
 
 CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full", "i45_prefix", "delft_prefix",
-         "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky", "odd_params", "odd_separators", "star8"]
+         "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky", "odd_params", "odd_separators", "star8", "edge_window_gt_T", "edge_empty"]
 
 
 def _dev_math(op, a, b=None, seed=0):

@@ -9,7 +9,7 @@ from golden_util import Golden, build_network
 from pednstream_amd.flatten import flatten_network
 
 CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full", "i45_prefix", "delft_prefix",
-         "melbourne_prefix", "forky", "odd_params", "odd_separators", "star8", "rand_nine_a", "rand_nine_b", "rand_delft_a",
+         "melbourne_prefix", "forky", "odd_params", "odd_separators", "star8", "edge_window_gt_T", "edge_empty", "rand_nine_a", "rand_nine_b", "rand_delft_a",
          "rand_delft_b", "randnet_i45_a", "randnet_i45_b", "randnet_nine"]
 
 
