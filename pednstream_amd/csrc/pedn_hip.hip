@@ -1,24 +1,15 @@
-// pedn_hip.hip -- MI355X (gfx950) engine for PedNStream's network_loading hot path: HIP kernels + C-ABI (include/pedn.h).
+// pedn_hip.hip -- host side of the MI355X (gfx950) engine for PedNStream's network_loading hot path: the C-ABI of
+// include/pedn.h (handle, device buffers, launches, host<->device transfers).  The kernels live in pedn_kernels.hpp, the
+// device data structures in pedn_types.hpp, the bit-exact arithmetic primitives in pedn_math.hpp.
 //
-// Data layout in HBM (DESIGN.md): every history field is one array [T+1][columns][RS] with the replica index
-// fastest (RS = replicas rounded up to a multiple of 128).  A wavefront therefore owns 64 consecutive replicas of ONE
-// link or node: topology and link parameters are wave-uniform (scalar loads), every history access of a wave is
-// one coalesced 256/512-byte row segment, and the data-dependent look-backs (cumulative_inflow[t+1-tau],
-// inflow[t-tau-k]) gather between rows of the same column.
+// Data layout in HBM (DESIGN.md section 4): every history field is one array [T+1][columns][RS] with the replica index
+// fastest (RS = replicas rounded up to a multiple of 128).  A wavefront owns 64 consecutive replicas of ONE link or node:
+// topology and link parameters are wave-uniform (scalar loads), every history access of a wave is one coalesced row
+// segment, and the data-dependent look-backs gather between rows of the same column.
 //
-// Kernels per step t (reference network.py:266-287):
-//   turn_prob_kernel  one lane per (softmax group, replica): P(down | up, od)      path_finder.py:561-589
-//   node_kernel       one wave per (node slot, 64 replicas), one block per bin of nodes with <= 8 slots in total:
-//                     sending flow of the slot's incoming link, receiving flow of its outgoing link, dynamic turning
-//                     fractions, the node's flow distribution through LDS, cumulative counts
-//                                                                                     node.py:164-221,230-242,272-300; link.py:216-416
-//   link_kernel       one lane per (corridor = link pair, replica): pedestrians, density, fundamental diagram,
-//                     travel time and its moving average                            link.py:133-188; functions.py:112-134
-//
-// Compile with -ffp-contract=off: results must match the reference bit for bit (cumulative counts) and the
-// arithmetic below spells out every binary32 / binary64 rounding point of numpy's scalar semantics.
-#include <hip/hip_runtime.h>
+// Compile with -ffp-contract=off: results must match the reference bit for bit.
 #include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -28,781 +19,7 @@
 #include <vector>
 
 #include "../../include/pedn.h"
-#include "pedn_math.hpp"
-
-using namespace pedn;
-
-// ------------------------------------------------------------------------------------------------- device view
-enum { F_IN = 0, F_OUT, F_CI, F_CO, F_S, F_R, F_GATE };
-enum { G_TT = 0, G_ATT, G_N, G_K, G_V, G_LF };
-
-struct LinkP {  // static per-link parameters, wave-uniform on the device
-  double length, width, vf, kc, kj, gamma, act, bi, noise;
-  float tt0;
-  int32_t rev, sep, fd, tau_sw, fft;
-  int32_t pad[2];
-};
-
-struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything static it needs, fetched by ONE scalar load burst
-  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, pad0, pad1;
-  LinkP Pin, Pout;  // parameters of the incoming / outgoing link of the slot (unused for a virtual pair)
-};
-
-struct CorrRec {  // one lane group of link_kernel: both directions of a corridor
-  int32_t a, b, pad0, pad1;
-  LinkP Pa, Pb;
-};
-
-struct EntS {  // one downstream entry of a softmax group (update_node_turn_probs, path_finder.py:561-589)
-  int32_t link, rev, sep;  // outgoing link (-1: virtual), its reverse, separator flag
-  float area32;            // float32(length * width) of a plain link
-  double vf, kc;           // for the capacity fallback back_gate * v_f * k_c * dt (:576)
-  double dist_term;        // alpha * distance / (sum of the group's distances + 1e-6), static (:582)
-};
-
-struct DevView {
-  double* f64[7];
-  float* f32[6];
-  float* rsum;
-  double *front, *back, *sepw, *sepnp, *tf, *demand, *ent_p;
-  // replica-uniform shortcuts (NaN = the value differs between replicas, read the per-replica row instead): a value every
-  // replica shares is one scalar load per wave instead of 8 bytes per lane
-  const double *front_u, *back_u;  // [L]
-  const double* tf_u;              // [n_turns]
-  // per-replica scenario parameters (randomised ensembles / RL resets, env_loader.py:363-424); used when pr != 0
-  const double *kc_r, *kj_r, *vf_r;   // [L][RS] k_critical, k_jam, free_flow_speed
-  const int32_t *fft_r, *tausw_r;     // [L][RS] free_flow_tau, shock-wave look-back
-  const float* tt0_r;                 // [L][RS] travel_time[0]
-  const double *pair_pod_r, *turn_tab_r;  // [n_pair][RS], [n_turns][RS]: P(od | up) with per-replica, time-constant OD weights
-  int32_t pr, pod_pr;
-  const double* od_w;
-  uint32_t* flags;
-  const LinkP* lp;
-  const SlotRec* slot_rec;
-  const CorrRec* corr_rec;
-  const int32_t *node_kind, *node_slot_ptr, *node_turn_ptr, *node_demand_row, *node_dyn, *slot_in, *slot_out;
-  const int32_t *grp_ent_ptr, *grp_allphys, *ent_pair, *turn_pair_ptr;
-  const struct EntS* ents;      // static per-entry data of the softmax groups
-  const int32_t* grp_multi;     // groups with more than one downstream entry (single-entry groups have P = 1 exactly)
-  const int32_t* pair_const;    // [n_pair] 1: the product's probability is the constant 1
-  const int32_t* turn_mode;     // [n_turns] 1: every product of the turn is constant -> fraction tabulated per step on the host
-  const double* turn_tab;       // [T+1][n_turns] tabulated raw fractions of such turns
-  const double* pair_pod;  // [T+1][n_pair] P(od | up) of the pair's upstream group, replica independent
-  int32_t L, Lall, T1, RS, R, W, n_grp, n_multi, n_pairs_corr, n_pair, n_turns;
-  double dt, pf_temp, pf_alpha, pf_beta, pf_omega, pf_eps;
-  uint32_t k0, k1, replica_offset;
-  int32_t meanfield;
-};
-
-__device__ __forceinline__ size_t at(int t, int col, int cols, int RS, int r) {
-  return ((size_t)t * (size_t)cols + (size_t)col) * (size_t)RS + (size_t)r;
-}
-__device__ __forceinline__ float clip01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
-// Link parameters as seen by one lane: the shared record, or (PR) the replica's own k_critical / k_jam / free-flow speed
-// and the quantities derived from them on the host.
-template <bool PR>
-__device__ __forceinline__ LinkP lane_params(const DevView& v, const LinkP& P, int l, int r) {
-  LinkP Q = P;
-  if (PR) {
-    const size_t i = (size_t)l * v.RS + r;
-    Q.kc = v.kc_r[i]; Q.kj = v.kj_r[i]; Q.vf = v.vf_r[i];
-    Q.fft = v.fft_r[i]; Q.tau_sw = v.tausw_r[i]; Q.tt0 = v.tt0_r[i];
-  }
-  return Q;
-}
-
-__device__ __forceinline__ int wrap_idx(int i, int T1, uint32_t& fl) {
-  if (i < 0) i += T1;
-  if (i < 0 || i >= T1) { fl |= PEDN_F_INDEX; return 0; }
-  return i;
-}
-
-// Link.get_density (link.py:190-197) / Separator.get_density (:427-428) at history index t
-__device__ __forceinline__ float dens_at(const DevView& v, const LinkP& P, int l, int t, int r) {
-  if (P.sep) return v.f32[G_K][at(t, l, v.L, v.RS, r)];
-  float n = v.f32[G_N][at(t, l, v.L, v.RS, r)] + v.f32[G_N][at(t, P.rev, v.L, v.RS, r)];
-  return n / (float)(P.length * P.width);
-}
-
-// Everything of step t' = t-1 a slot wave needs from HBM whose address does not depend on data: fetched as ONE batch of
-// independent loads at the top of node_kernel (the wave then waits once instead of once per dependent use; the kernel is
-// latency-bound: 76 % of its wave-cycles were s_waitcnt with the loads left where the formulas use them).
-struct SlotIn {
-  float n_in, n_out, k_in, att_in;        // num_pedestrians[t'] of the incoming / outgoing link, density and avg travel time
-  double co_in, s_prev, front_in, sepw_in;   // incoming link: cumulative_outflow[t'], sending_flow[t'-1], front gate, separator width
-  double co_sw, ci_out, r_prev, back_out, sepw_out;  // outgoing link: cumulative_outflow[t'+1-tau_sw], cumulative_inflow[t'],
-                                                     // receiving_flow[t'-1], back gate, separator width
-};
-
-// Link.cal_sending_flow (link.py:216-370) incl. get_outflow (:199-214) for t' >= free_flow_tau
-__device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, uint32_t& fl) {
-  const int RS = v.RS, T1 = v.T1;
-  const float nself = x.n_in, nrev = x.n_out, kk = x.k_in, att = x.att_in;
-  double aw = P.sep ? x.sepw_in : P.width;
-  float dens = P.sep ? kk : (nself + nrev) / (float)(P.length * aw);
-  int tau = __float2int_rn(att / (float)v.dt);  // link.py:260
-  if (tau <= 0) fl |= PEDN_F_SAME_STEP;
-  int idx = tp + 1 - tau;
-  if (idx < 0) idx = 0;
-  float cf = clip01((kk - (float)P.kc) / (float)(P.kj - P.kc));  // link.py:282
-  double ff = v.f64[F_CI][at(idx, l, v.Lall, RS, r)] - x.co_in;  // the one data-dependent look-back of the common path
-  if (!(ff > 0.0)) ff = 0.0;
-  double bnd = (double)(cf * nself) + (double)(1.0f - cf) * ff;  // link.py:284-288
-  double smax = x.front_in * P.kc * P.vf * v.dt;                 // link.py:296
-  double s = smax < bnd ? smax : bnd;
-  double orig = s;
-  RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)tp, 0u};
-  if (s > 0.0) {
-    float rf = clip01(dens / (float)P.kj);                          // link.py:315
-    float p = 0.7f + (float)(0.85 - 0.7) * pedn_powf(rf, 0.8f);     // link.py:317
-    bool diffusion_used = false;
-    if (dens <= (float)P.kc) {  // link.py:323
-      float F = 1.0f / (1.0f + (float)P.gamma * att);
-      float G = 1.0f - F;
-      const double* in = v.f64[F_IN];
-      double i0 = in[at(wrap_idx(tp - tau, T1, fl), l, v.Lall, RS, r)], i1 = in[at(wrap_idx(tp - tau - 1, T1, fl), l, v.Lall, RS, r)];
-      double i2 = in[at(wrap_idx(tp - tau - 2, T1, fl), l, v.Lall, RS, r)], i3 = in[at(wrap_idx(tp - tau - 3, T1, fl), l, v.Lall, RS, r)];
-      float G2, G3;
-      pedn_powf_2_3(G, G2, G3);
-      double d = (double)F * i0 + (double)(F * G) * i1 + (double)(F * G2) * i2 + (double)(F * G3) * i3;
-      d = ceil(d);
-      if (d > 0.0) {  // link.py:326-330
-        double mix = 0.8 * d + (1 - 0.8) * s;
-        s = floor(mix < s ? mix : s);
-        diffusion_used = true;
-      }
-    }
-    if (!diffusion_used) {  // link.py:336-338,342-344
-      key.site = 0u;
-      s = rng_binomial((long long)floor(s), (double)p, key, v.meanfield);
-    }
-    if (s < 0.0) fl |= PEDN_F_NEG_SENDING;
-  }
-  if (P.act > 0.0 && s > 1.0) {  // link.py:351-358
-    key.site = 1u;
-    s -= rng_binomial((long long)floor(s), P.act, key, v.meanfield);
-  }
-  if (!(s > 0.0)) s = 0.0;
-  double sm = floor(0.8 * s + 0.2 * x.s_prev);  // link.py:364
-  s = orig < sm ? orig : sm;
-  if (s < 0.0) fl |= PEDN_F_NEG_SENDING;
-  return s;
-}
-
-// Link/Separator.cal_receiving_flow[_with_reverse] (link.py:372-416,480-512); the reverse link is the slot's incoming link
-__device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, double s_rev, uint32_t& fl) {
-  const float nrev = x.n_in;
-  double aw = P.sep ? x.sepw_out : P.width;
-  double kjA = P.kj * (P.length * aw);
-  int tsw = P.tau_sw;
-  double b;
-  if (P.sep) {
-    if (tp + 1 - tsw < 0) b = kjA;
-    else {
-      if (tsw <= 0) fl |= PEDN_F_SAME_STEP;
-      b = x.co_sw + kjA - x.ci_out;
-    }
-  } else {
-    if (nrev < 0.0f) fl |= PEDN_F_NEG_BINOM;
-    RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)tp, 2u};
-    double rp = rng_binomial((long long)nrev, 0.9, key, v.meanfield);  // link.py:381-382
-    if (tp + 1 - tsw < 0) b = kjA - rp;
-    else {
-      if (tsw <= 0) fl |= PEDN_F_SAME_STEP;
-      b = x.co_sw + kjA - rp - x.ci_out;
-      if (!(b > 0.0)) b = 0.0;
-    }
-  }
-  double rmax = x.back_out * P.kc * P.vf * v.dt;  // link.py:393
-  double rr = rmax < b ? rmax : b;
-  if (!(rr > 0.0)) rr = 0.0;
-  if (x.r_prev >= 0.0) {  // link.py:400-401
-    double sm = floor(rr * 0.8 + x.r_prev * 0.2);
-    rr = sm < rr ? sm : rr;
-  }
-  if (P.sep) return rr > 0.0 ? rr : 0.0;
-  rr = rr - s_rev;  // link.py:415-416
-  return rr > 0.0 ? rr : 0.0;
-}
-
-// ------------------------------------------------------------------------------------------------- kernels
-// P(down | up, od) for every softmax group with more than one downstream (update_node_turn_probs, path_finder.py:561-589).
-// A group with a single downstream has P = e/e = 1 exactly; those are constants and never recomputed.
-template <bool PR>
-__global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
-  const int RS = v.RS;
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int gi = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
-  int r = (int)(gid % (size_t)RS);
-  if (gi >= v.n_multi) return;
-  const int g = v.grp_multi[gi];
-  uint32_t fl = 0;
-  const int a = v.grp_ent_ptr[g], n = v.grp_ent_ptr[g + 1] - a;
-  const int allphys = v.grp_allphys[g];
-  const int t2 = wrap_idx(t - 2, v.T1, fl);
-  double cap[PEDN_MAX_DEGREE - 1];
-  float kf[PEDN_MAX_DEGREE - 1];
-  double sumc = 0.0;
-#pragma unroll
-  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
-    if (e < n) {
-      const EntS E = v.ents[a + e];
-      if (E.link >= 0) {
-        if (E.sep) kf[e] = v.f32[G_K][at(t - 1, E.link, v.L, RS, r)];  // Separator.get_density, link.py:427-428
-        else kf[e] = (v.f32[G_N][at(t - 1, E.link, v.L, RS, r)] + v.f32[G_N][at(t - 1, E.rev, v.L, RS, r)]) / E.area32;
-        double c = v.f64[F_R][at(t2, E.link, v.L, RS, r)];
-        if (!(c >= 0.0)) {
-          const double vf = PR ? v.vf_r[(size_t)E.link * RS + r] : E.vf, kc = PR ? v.kc_r[(size_t)E.link * RS + r] : E.kc;
-          c = v.back[(size_t)E.link * RS + r] * vf * kc * v.dt;  // :575-576
-        }
-        cap[e] = c;
-      } else {
-        kf[e] = 0.0f;
-        cap[e] = 100.0;  // :577-579
-      }
-      sumc = (e == 0) ? cap[e] : sumc + cap[e];
-    }
-  }
-  double ex[PEDN_MAX_DEGREE - 1];
-  double esum = 0.0;
-#pragma unroll
-  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
-    if (e < n) {
-      double nd;
-      if (allphys) {  // float32 array branch of :581,583
-        float x = kf[e] - 2.0f;
-        if (!(x > 0.0f)) x = 0.0f;
-        nd = (double)((float)v.pf_beta * (x / 8.0f));
-      } else {
-        double x = (double)kf[e] - 2.0;
-        if (!(x > 0.0)) x = 0.0;
-        nd = v.pf_beta * (x / 8.0);
-      }
-      double u = v.ents[a + e].dist_term + nd - (v.pf_omega * cap[e]) / (sumc + 1e-6) + v.pf_eps;
-      ex[e] = pedn_exp(-v.pf_temp * u);
-      esum = (e == 0) ? ex[e] : esum + ex[e];
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
-    if (e < n) {
-      const int q = v.ent_pair[a + e];  // slot of the (turn, od) product that consumes this probability
-      if (q >= 0) v.ent_p[(size_t)q * RS + r] = ex[e] / esum;
-    }
-  }
-  if (fl) atomicOr(&v.flags[r], fl);
-}
-
-// One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
-template <bool PR>
-__global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
-  __shared__ double sPS[64 * 64];  // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
-  __shared__ double sR[8 * 64];    // receiving flow of each wave's outgoing link
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = (int)(threadIdx.x & 63);
-  const int RS = v.RS, L = v.L, Lall = v.Lall;
-  // blockIdx.x = replica group (fastest in dispatch order): blocks launched together touch neighbouring 512-byte chunks
-  // of the same history rows
-  const int r = (int)blockIdx.x * 64 + lane;
-  const int tp = t - 1;
-  const SlotRec& W = v.slot_rec[(size_t)blockIdx.y * 8 + wave];  // wave-uniform: scalar loads
-  const int node = W.node, slot = W.slot, base = W.base, m = W.m;
-  const bool active = node >= 0;
-  uint32_t fl = 0;
-  double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0, co_prev = 0.0, ci_prev = 0.0;
-  int lin = 0, lout = 0, kind = 0;
-  double tfr[PEDN_MAX_DEGREE - 1];
-
-  if (active) {
-    kind = W.kind;
-    lin = W.lin;
-    lout = W.lout;
-    const int turn0 = W.turn0 + slot * (m - 1);
-    const bool static_tf = kind == 1 && !W.dyn;
-    if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
-      s_i = v.demand[((size_t)W.demand_row * v.T1 + tp) * RS + r];
-      co_prev = v.f64[F_CO][at(tp, lin, Lall, RS, r)];
-      ci_prev = v.f64[F_CI][at(tp, lout, Lall, RS, r)];
-      if (static_tf) {
-        const bool shared = v.tf_u[turn0] == v.tf_u[turn0];  // not NaN
-#pragma unroll
-        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
-          if (jj < m - 1) tfr[jj] = shared ? v.tf_u[turn0 + jj] : v.tf[(size_t)(turn0 + jj) * RS + r];
-      }
-      r_i = 1e6;
-    } else {
-      const LinkP Pin = lane_params<PR>(v, W.Pin, lin, r);
-      const LinkP Pout = lane_params<PR>(v, W.Pout, lout, r);
-      const bool early = tp < Pin.fft;  // link.py:267-269: sending flow is 0 until the first pedestrians can arrive
-      uint32_t flw = 0;
-      const int tm1 = wrap_idx(tp - 1, v.T1, flw);
-      fl |= flw;
-      // ---- one batch of independent loads (see SlotIn): straight-line and unconditional so that the compiler issues them
-      // back to back (a load skipped by a branch costs a wait at the join); the few values of an `early` step are unused
-      SlotIn x;
-      const int t_sw = tp + 1 - Pout.tau_sw > 0 ? tp + 1 - Pout.tau_sw : 0;
-      x.n_in = v.f32[G_N][at(tp, lin, L, RS, r)];
-      x.n_out = v.f32[G_N][at(tp, lout, L, RS, r)];
-      x.k_in = v.f32[G_K][at(tp, lin, L, RS, r)];
-      x.att_in = v.f32[G_ATT][at(tp, lin, L, RS, r)];
-      x.co_in = v.f64[F_CO][at(tp, lin, Lall, RS, r)];
-      x.s_prev = v.f64[F_S][at(tm1, lin, L, RS, r)];
-      x.co_sw = v.f64[F_CO][at(t_sw, lout, Lall, RS, r)];
-      x.ci_out = v.f64[F_CI][at(tp, lout, Lall, RS, r)];
-      x.r_prev = v.f64[F_R][at(tm1, lout, L, RS, r)];
-      const double fu = v.front_u[lin], bu = v.back_u[lout];
-      x.front_in = fu == fu ? fu : v.front[(size_t)lin * RS + r];
-      x.back_out = bu == bu ? bu : v.back[(size_t)lout * RS + r];
-      x.sepw_in = Pin.sep ? v.sepw[(size_t)lin * RS + r] : 0.0;
-      x.sepw_out = Pout.sep ? v.sepw[(size_t)lout * RS + r] : 0.0;
-      if (static_tf) {
-        const bool shared = v.tf_u[turn0] == v.tf_u[turn0];  // not NaN
-#pragma unroll
-        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
-          if (jj < m - 1) tfr[jj] = shared ? v.tf_u[turn0 + jj] : v.tf[(size_t)(turn0 + jj) * RS + r];
-      }
-      co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
-      ci_prev = x.ci_out;  // cumulative_inflow[t-1] of the outgoing link
-      s_i = early ? 0.0 : send_flow(v, Pin, lin, tp, r, x, fl);
-      v.f64[F_S][at(tp, lin, L, RS, r)] = s_i;  // link.py:268,367
-      if (s_i < 0.0) fl |= PEDN_F_NEG_FLOW;
-      r_i = recv_flow(v, Pout, lout, tp, r, x, s_i, fl);
-      v.f64[F_R][at(tp, lout, L, RS, r)] = r_i;  // node.py:206
-    }
-    if (s_i < 0.0 || r_i < 0.0) fl |= PEDN_F_NEG_FLOW;
-
-    if (kind == 1) {
-      // turning fractions of row `slot`: static, or recomputed from the route-choice tables (path_finder.py:591-715)
-      if (W.dyn) {
-        // tf[turn] = sum over the turn's (od) products P(down | up, od) * P(od | up)   (path_finder.py:668-686).
-        // The products of one row are contiguous: probabilities were stored in pair order by turn_prob_kernel and
-        // P(od | up) (replica independent, :599-615) was tabulated per pair and step on the host.
-        const double* pod = v.pair_pod + (size_t)t * v.n_pair;
-        const bool ppr = v.pod_pr != 0;  // per-replica OD weights: tables indexed [product][replica] instead of [step][product]
-        double rowsum = 0.0;
-#pragma unroll
-        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
-          if (jj < m - 1) {
-            double acc = 0.0;
-            const int q1 = v.turn_mode[turn0 + jj] ? 0 : v.turn_pair_ptr[turn0 + jj + 1];
-            if (v.turn_mode[turn0 + jj]) acc = ppr ? v.turn_tab_r[(size_t)(turn0 + jj) * RS + r] : v.turn_tab[(size_t)t * v.n_turns + turn0 + jj];
-            for (int q = v.turn_pair_ptr[turn0 + jj]; q < q1; q += 4) {
-              // loads first (independent), then the strictly sequential sum the reference performs
-              double e0 = v.pair_const[q] ? 1.0 : v.ent_p[(size_t)q * RS + r];
-              double e1 = q + 1 < q1 ? (v.pair_const[q + 1] ? 1.0 : v.ent_p[(size_t)(q + 1) * RS + r]) : 0.0;
-              double e2 = q + 2 < q1 ? (v.pair_const[q + 2] ? 1.0 : v.ent_p[(size_t)(q + 2) * RS + r]) : 0.0;
-              double e3 = q + 3 < q1 ? (v.pair_const[q + 3] ? 1.0 : v.ent_p[(size_t)(q + 3) * RS + r]) : 0.0;
-              acc += e0 * (ppr ? v.pair_pod_r[(size_t)q * RS + r] : pod[q]);
-              if (q + 1 < q1) acc += e1 * (ppr ? v.pair_pod_r[(size_t)(q + 1) * RS + r] : pod[q + 1]);
-              if (q + 2 < q1) acc += e2 * (ppr ? v.pair_pod_r[(size_t)(q + 2) * RS + r] : pod[q + 2]);
-              if (q + 3 < q1) acc += e3 * (ppr ? v.pair_pod_r[(size_t)(q + 3) * RS + r] : pod[q + 3]);
-            }
-            tfr[jj] = acc;
-            rowsum = (jj == 0) ? acc : rowsum + acc;
-          }
-        }
-        const bool renorm = fabs(rowsum - 1) > 1e-3;  // check_fractions, :700-714
-#pragma unroll
-        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
-          if (jj < m - 1) {
-            if (renorm) tfr[jj] = rowsum > 1e-6 ? tfr[jj] / rowsum : 1.0 / (double)(m - 1);
-            v.tf[(size_t)(turn0 + jj) * RS + r] = tfr[jj];
-          }
-        }
-      }
-      // P[i][j] * s_i  (node.py:285)
-#pragma unroll
-      for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
-        if (jj < m - 1) {
-          const int j = jj < slot ? jj : jj + 1;
-          sPS[(size_t)(base + slot * m + j) * 64 + lane] = tfr[jj] * s_i;
-        }
-      }
-    } else {
-      sPS[(size_t)(base + slot) * 64 + lane] = s_i;
-    }
-    sR[wave * 64 + lane] = r_i;
-  }
-  __syncthreads();
-
-  if (active && kind == 1) {
-    // column `slot`: D_j = sum_i P[i][j] s_i (i ascending), g_ij = floor(min(P s, r_j * (P s / D_j)))  (node.py:286-298)
-    double D = 0.0;
-    bool first = true;
-#pragma unroll
-    for (int k = 0; k < PEDN_MAX_DEGREE; ++k) {
-      if (k < m && k != slot) {
-        double x = sPS[(size_t)(base + k * m + slot) * 64 + lane];
-        D = first ? x : D + x;
-        first = false;
-      }
-    }
-    const double Ds = D != 0.0 ? D : 1e-5;
-#pragma unroll
-    for (int k = 0; k < PEDN_MAX_DEGREE; ++k) {
-      if (k < m && k != slot) {
-        double a = sPS[(size_t)(base + k * m + slot) * 64 + lane];
-        double b = r_i * (a / Ds);
-        double g = floor(b < a ? b : a);
-        sPS[(size_t)(base + k * m + slot) * 64 + lane] = g;
-        qi += g;
-      }
-    }
-  }
-  __syncthreads();
-
-  if (active) {
-    if (kind == 1) {
-#pragma unroll
-      for (int j = 0; j < PEDN_MAX_DEGREE; ++j)
-        if (j < m && j != slot) qo += sPS[(size_t)(base + slot * m + j) * 64 + lane];
-      if (!(qo > 0.0)) qo = 0.0;  // np.maximum(0, flows), node.py:299
-      if (!(qi > 0.0)) qi = 0.0;
-    } else {  // OneToOneNode.solve (node.py:230-242), not floored
-      const int other = 1 - slot;
-      double s_o = sPS[(size_t)(base + other) * 64 + lane];
-      double r_o = sR[(wave - slot + other) * 64 + lane];
-      qo = s_i < r_o ? s_i : r_o;
-      qi = s_o < r_i ? s_o : r_i;
-      if (qo < 0.0 || qi < 0.0) fl |= PEDN_F_NEG_FLOW;
-    }
-    // Node.update_links (node.py:146-162; link.py:19-25)
-    v.f64[F_OUT][at(t, lin, Lall, RS, r)] = qo;
-    v.f64[F_CO][at(t, lin, Lall, RS, r)] = co_prev + qo;
-    v.f64[F_IN][at(t, lout, Lall, RS, r)] = qi;
-    v.f64[F_CI][at(t, lout, Lall, RS, r)] = ci_prev + qi;
-    if (fl) atomicOr(&v.flags[r], fl);
-  }
-}
-
-// BiDirectionalFd.__call__ + the travel-time part of Link.update_speeds for one direction and one replica; pure arithmetic
-struct SpeedOut { float spd, tt, lf, att, rs; };
-
-__device__ __forceinline__ SpeedOut speed_calc(const DevView& v, const LinkP& P, int l, int t, int r, float ks, float ko,
-                                               float rsum_prev, float tt_old) {
-  float ke = P.sep ? ks : ks + (float)P.bi * ko;  // functions.py:113
-  bool is64;  // true: the speed is a Python float (binary64) at this point, false: np.float32
-  double v64 = 0.0;
-  float v32 = 0.0f;
-  if (P.fd == 2 && ke <= (float)P.kc) {
-    v32 = (float)P.vf * (1.0f - ke / (float)P.kj);
-    is64 = false;
-  } else if (ke <= (float)P.kc) {
-    v64 = P.vf;
-    is64 = true;
-  } else {
-    if (P.fd == 0) v32 = (float)((P.kc * P.vf) / (P.kj - P.kc)) * ((float)P.kj / ke - 1.0f);
-    else if (P.fd == 1) v32 = ((float)(-P.vf) * (ke - (float)P.kj)) / (float)(P.kj - P.kc);
-    else v32 = (float)(P.vf * P.kc) * (1.0f / ke - (float)(1 / P.kj));
-    is64 = false;
-    if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }  // Python max(0, x) returns the int 0
-  }
-  if (P.noise > 0.0) {  // functions.py:132-133
-    double nz = 0.0;
-    if (!v.meanfield) {
-      RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)t, 3u};
-      nz = P.noise * rng_z(key);
-    }
-    if (is64) v64 = v64 + nz;
-    else v32 = v32 + (float)nz;
-  }
-  if (is64) { if (!(v64 > 0.0)) v64 = 0.0; }
-  else if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }
-  SpeedOut o;
-  o.spd = is64 ? (float)v64 : v32;
-  if (is64) o.tt = v64 > 0.0 ? (float)(P.length / v64) : (float)(P.length / 0.05);  // link.py:177
-  else o.tt = (float)P.length / v32;
-  o.lf = ks * o.spd;               // link.py:181
-  o.rs = rsum_prev + o.tt;         // link.py:183-186, float32 running sum
-  o.att = P.tt0;
-  if (t >= v.W) {
-    o.rs = o.rs - tt_old;
-    o.att = o.rs / (float)v.W;
-  }
-  return o;
-}
-
-__device__ __forceinline__ double2 ld2(const double* p, size_t i) { return *reinterpret_cast<const double2*>(p + i); }
-__device__ __forceinline__ float2 ld2(const float* p, size_t i) { return *reinterpret_cast<const float2*>(p + i); }
-__device__ __forceinline__ void st2(double* p, size_t i, double a, double b) { *reinterpret_cast<double2*>(p + i) = make_double2(a, b); }
-__device__ __forceinline__ void st2(float* p, size_t i, float a, float b) { *reinterpret_cast<float2*>(p + i) = make_float2(a, b); }
-
-// Network.update_link_states (network.py:257-264).  One lane = both directions of one corridor for TWO adjacent replicas:
-// every history access is a 16-byte (f64) or 8-byte (f32) vector access, i.e. 1 KiB / 512 B per wave instruction.
-__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) {
-  const int RS = v.RS, L = v.L, Lall = v.Lall, H = RS / 2;
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)H));
-  const int r = 2 * (int)(gid % (size_t)H);
-  if (p >= v.n_pairs_corr) return;
-  const CorrRec& C = v.corr_rec[p];  // wave-uniform
-  const int a = C.a, b = C.b;
-  const LinkP& Pa = C.Pa;
-  const LinkP& Pb = C.Pb;
-  const bool win = t >= v.W;
-  // ---- loads
-  const double2 ina = ld2(v.f64[F_IN], at(t, a, Lall, RS, r)), outa = ld2(v.f64[F_OUT], at(t, a, Lall, RS, r));
-  const double2 inb = ld2(v.f64[F_IN], at(t, b, Lall, RS, r)), outb = ld2(v.f64[F_OUT], at(t, b, Lall, RS, r));
-  const float2 pa = ld2(v.f32[G_N], at(t - 1, a, L, RS, r)), pb = ld2(v.f32[G_N], at(t - 1, b, L, RS, r));
-  const float2 rsa = ld2(v.rsum, (size_t)a * RS + r), rsb = ld2(v.rsum, (size_t)b * RS + r);
-  const float2 oa = win ? ld2(v.f32[G_TT], at(t - v.W, a, L, RS, r)) : make_float2(0.f, 0.f);
-  const float2 ob = win ? ld2(v.f32[G_TT], at(t - v.W, b, L, RS, r)) : make_float2(0.f, 0.f);
-  const double bua = v.back_u[a], bub = v.back_u[b];
-  double2 wa = make_double2(Pa.width, Pa.width), wb = make_double2(Pb.width, Pb.width), fa = make_double2(0, 0), fb = make_double2(0, 0);
-  if (Pa.sep) { wa = ld2(v.sepw, (size_t)a * RS + r); fa = ld2(v.sepnp, (size_t)a * RS + r); }
-  if (Pb.sep) { wb = ld2(v.sepw, (size_t)b * RS + r); fb = ld2(v.sepnp, (size_t)b * RS + r); }
-  double2 ga = Pa.sep ? wa : make_double2(bua, bua), gb = Pb.sep ? wb : make_double2(bub, bub);  // recorded width (link.py:188 / :451-452)
-  if (!Pa.sep && !(bua == bua)) ga = ld2(v.back, (size_t)a * RS + r);
-  if (!Pb.sep && !(bub == bub)) gb = ld2(v.back, (size_t)b * RS + r);
-  // ---- per replica arithmetic (link.py:133-136, then update_speeds)
-  float na[2], nb[2], ka[2], kb[2];
-  SpeedOut sa[2], sb[2];
-  const double dina[2] = {ina.x - outa.x, ina.y - outa.y}, dinb[2] = {inb.x - outb.x, inb.y - outb.y};
-  const float pav[2] = {pa.x, pa.y}, pbv[2] = {pb.x, pb.y};
-  const double wav[2] = {wa.x, wa.y}, wbv[2] = {wb.x, wb.y}, fav[2] = {fa.x, fa.y}, fbv[2] = {fb.x, fb.y};
-  const float rsav[2] = {rsa.x, rsa.y}, rsbv[2] = {rsb.x, rsb.y}, oav[2] = {oa.x, oa.y}, obv[2] = {ob.x, ob.y};
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    na[j] = (float)((double)pav[j] + dina[j]);
-    nb[j] = (float)((double)pbv[j] + dinb[j]);
-    // a separator width held as np.float64 turns the division into binary64 (PEDN_W_SEP_NUMPY)
-    ka[j] = (Pa.sep && fav[j] != 0.0) ? (float)((double)na[j] / (Pa.length * wav[j])) : na[j] / (float)(Pa.length * wav[j]);
-    kb[j] = (Pb.sep && fbv[j] != 0.0) ? (float)((double)nb[j] / (Pb.length * wbv[j])) : nb[j] / (float)(Pb.length * wbv[j]);
-    sa[j] = speed_calc(v, Pa, a, t, r + j, ka[j], kb[j], rsav[j], oav[j]);
-    sb[j] = speed_calc(v, Pb, b, t, r + j, kb[j], ka[j], rsbv[j], obv[j]);
-  }
-  // ---- stores
-  st2(v.f32[G_N], at(t, a, L, RS, r), na[0], na[1]);
-  st2(v.f32[G_N], at(t, b, L, RS, r), nb[0], nb[1]);
-  st2(v.f32[G_K], at(t, a, L, RS, r), ka[0], ka[1]);
-  st2(v.f32[G_K], at(t, b, L, RS, r), kb[0], kb[1]);
-  st2(v.f32[G_V], at(t, a, L, RS, r), sa[0].spd, sa[1].spd);
-  st2(v.f32[G_V], at(t, b, L, RS, r), sb[0].spd, sb[1].spd);
-  st2(v.f32[G_TT], at(t, a, L, RS, r), sa[0].tt, sa[1].tt);
-  st2(v.f32[G_TT], at(t, b, L, RS, r), sb[0].tt, sb[1].tt);
-  st2(v.f32[G_LF], at(t, a, L, RS, r), sa[0].lf, sa[1].lf);
-  st2(v.f32[G_LF], at(t, b, L, RS, r), sb[0].lf, sb[1].lf);
-  if (win) {
-    st2(v.f32[G_ATT], at(t, a, L, RS, r), sa[0].att, sa[1].att);
-    st2(v.f32[G_ATT], at(t, b, L, RS, r), sb[0].att, sb[1].att);
-  }
-  st2(v.rsum, (size_t)a * RS + r, sa[0].rs, sa[1].rs);
-  st2(v.rsum, (size_t)b * RS + r, sb[0].rs, sb[1].rs);
-  // the record is initialised to `width` (link.py:56), so an unchanged gate needs no store
-  if (ga.x != Pa.width || ga.y != Pa.width) st2(v.f64[F_GATE], at(t, a, L, RS, r), ga.x, ga.y);
-  if (gb.x != Pb.width || gb.y != Pb.width) st2(v.f64[F_GATE], at(t, b, L, RS, r), gb.x, gb.y);
-}
-
-// Same update with per-replica link parameters: one replica per lane (the parameters live in vector registers).
-__global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) {
-  const int RS = v.RS, L = v.L, Lall = v.Lall;
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
-  const int r = (int)(gid % (size_t)RS);
-  if (p >= v.n_pairs_corr) return;
-  const CorrRec& C = v.corr_rec[p];
-  const int a = C.a, b = C.b;
-  const LinkP Pa = lane_params<true>(v, C.Pa, a, r), Pb = lane_params<true>(v, C.Pb, b, r);
-  const bool win = t >= v.W;
-  const double da = v.f64[F_IN][at(t, a, Lall, RS, r)] - v.f64[F_OUT][at(t, a, Lall, RS, r)];
-  const double db = v.f64[F_IN][at(t, b, Lall, RS, r)] - v.f64[F_OUT][at(t, b, Lall, RS, r)];
-  const float na = (float)((double)v.f32[G_N][at(t - 1, a, L, RS, r)] + da), nb = (float)((double)v.f32[G_N][at(t - 1, b, L, RS, r)] + db);
-  const double wa = Pa.sep ? v.sepw[(size_t)a * RS + r] : Pa.width, wb = Pb.sep ? v.sepw[(size_t)b * RS + r] : Pb.width;
-  const float ka = (Pa.sep && v.sepnp[(size_t)a * RS + r] != 0.0) ? (float)((double)na / (Pa.length * wa)) : na / (float)(Pa.length * wa);
-  const float kb = (Pb.sep && v.sepnp[(size_t)b * RS + r] != 0.0) ? (float)((double)nb / (Pb.length * wb)) : nb / (float)(Pb.length * wb);
-  const float oa = win ? v.f32[G_TT][at(t - v.W, a, L, RS, r)] : 0.0f, ob = win ? v.f32[G_TT][at(t - v.W, b, L, RS, r)] : 0.0f;
-  const SpeedOut sa = speed_calc(v, Pa, a, t, r, ka, kb, v.rsum[(size_t)a * RS + r], oa);
-  const SpeedOut sb = speed_calc(v, Pb, b, t, r, kb, ka, v.rsum[(size_t)b * RS + r], ob);
-  const double ga = Pa.sep ? wa : v.back[(size_t)a * RS + r], gb = Pb.sep ? wb : v.back[(size_t)b * RS + r];
-  v.f32[G_N][at(t, a, L, RS, r)] = na; v.f32[G_N][at(t, b, L, RS, r)] = nb;
-  v.f32[G_K][at(t, a, L, RS, r)] = ka; v.f32[G_K][at(t, b, L, RS, r)] = kb;
-  v.f32[G_V][at(t, a, L, RS, r)] = sa.spd; v.f32[G_V][at(t, b, L, RS, r)] = sb.spd;
-  v.f32[G_TT][at(t, a, L, RS, r)] = sa.tt; v.f32[G_TT][at(t, b, L, RS, r)] = sb.tt;
-  v.f32[G_LF][at(t, a, L, RS, r)] = sa.lf; v.f32[G_LF][at(t, b, L, RS, r)] = sb.lf;
-  if (win) { v.f32[G_ATT][at(t, a, L, RS, r)] = sa.att; v.f32[G_ATT][at(t, b, L, RS, r)] = sb.att; }
-  v.rsum[(size_t)a * RS + r] = sa.rs; v.rsum[(size_t)b * RS + r] = sb.rs;
-  if (ga != Pa.width) v.f64[F_GATE][at(t, a, L, RS, r)] = ga;
-  if (gb != Pb.width) v.f64[F_GATE][at(t, b, L, RS, r)] = gb;
-}
-
-// ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------
-struct RlView {
-  const int32_t *agent_type, *agent_link_ptr, *agent_links, *agent_act_off, *agent_obs_off;
-  const int32_t *slot_agent, *slot_idx;  // action slot -> (agent, position in the agent's link list)
-  double* actions;                        // [R][A]
-  float *obs, *rew;                       // [R][O], [R][n_agents]
-  int32_t n_agents, A, O, obs_mode, normalize, reward_mode, fpl;
-  double max_delta_sep, max_delta_gate, min_sep;
-};
-
-__device__ __forceinline__ double clip_d(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }  // np.clip
-
-// ActionApplier (builders.py:281-352): one lane per (action slot, replica)
-__global__ void rl_apply_kernel(DevView v, RlView q) {
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int a = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)v.RS));  // RS is a multiple of 128: uniform per wave
-  const int r = (int)(gid % (size_t)v.RS);
-  if (a >= q.A || r >= v.R) return;
-  const int ag = q.slot_agent[a], i = q.slot_idx[a];
-  const int l = q.agent_links[q.agent_link_ptr[ag] + i];
-  const LinkP P = v.lp[l];
-  double x = q.actions[(size_t)r * q.A + a];
-  if (q.agent_type[ag] == 0) {  // separator: clip_separator_action_value + Separator.separator_width setter (link.py:462-478)
-    const double cur = v.sepw[(size_t)l * v.RS + r];
-    if (fabs(x - cur) > q.max_delta_sep) x = cur + clip_d(x - cur, -q.max_delta_sep, q.max_delta_sep);
-    x = clip_d(x, q.min_sep, P.width - q.min_sep);
-    const double other = P.width - x;
-    v.sepnp[(size_t)l * v.RS + r] = 1.0; v.sepnp[(size_t)P.rev * v.RS + r] = 1.0;  // np.clip returns np.float64
-    v.sepw[(size_t)l * v.RS + r] = x; v.front[(size_t)l * v.RS + r] = x; v.back[(size_t)l * v.RS + r] = x;
-    v.sepw[(size_t)P.rev * v.RS + r] = other; v.front[(size_t)P.rev * v.RS + r] = other; v.back[(size_t)P.rev * v.RS + r] = other;
-  } else {  // gater: clip_gater_action_value + back_gate_width setter (link.py:121-126)
-    const double cur = v.back[(size_t)l * v.RS + r];
-    if (fabs(x - cur) > q.max_delta_gate) x = cur + clip_d(x - cur, -q.max_delta_gate, q.max_delta_gate);
-    x = clip_d(x, 0.0, P.width);
-    v.back[(size_t)l * v.RS + r] = x;
-    v.front[(size_t)P.rev * v.RS + r] = x;
-  }
-}
-
-// ObservationBuilder + _compute_rewards.  Block = (agent, 64 replicas); wave w = the agent's w-th controlled link: its
-// features go straight to the observation row, its reward terms to LDS; wave 0 then folds them in the reference's order.
-__global__ __launch_bounds__(512) void rl_observe_kernel(DevView v, RlView q, int t, int accumulate) {
-  __shared__ float sT[PEDN_MAX_DEGREE][64], sD[PEDN_MAX_DEGREE][64], sKc[PEDN_MAX_DEGREE][64];
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = (int)(threadIdx.x & 63);
-  const int r = (int)blockIdx.x * 64 + lane;
-  const int ag = (int)blockIdx.y;
-  const int RS = v.RS, L = v.L, Lall = v.Lall;
-  const int la = q.agent_link_ptr[ag], n = q.agent_link_ptr[ag + 1] - la;
-  const int type = q.agent_type[ag];
-  const bool live = r < v.R;
-  float* o = q.obs + (size_t)(live ? r : 0) * q.O + q.agent_obs_off[ag];
-  if (type == 0) {  // separator agent, builders.py:87-117
-    if (w == 0 && live) {
-      const int f = q.agent_links[la], b = q.agent_links[la + 1];
-      float x[4] = {(float)v.f64[F_IN][at(t, f, Lall, RS, r)], (float)v.f64[F_OUT][at(t, f, Lall, RS, r)],
-                    (float)v.f64[F_IN][at(t, b, Lall, RS, r)], (float)v.f64[F_OUT][at(t, b, Lall, RS, r)]};
-      for (int k = 0; k < 4; ++k) {
-        if (q.normalize && (q.obs_mode == 1 || q.obs_mode == 2)) x[k] = x[k] / 20.0f;  // builders.py:183-188
-        o[k] = x[k];
-      }
-    }
-  } else if (w < n) {  // gater agent, link w: builders.py:119-177
-    const int l = q.agent_links[la + w];
-    const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
-    const float in_l = (float)v.f64[F_IN][at(t, l, Lall, RS, r)], out_l = (float)v.f64[F_OUT][at(t, l, Lall, RS, r)];
-    const float in_r = (float)v.f64[F_IN][at(t, P.rev, Lall, RS, r)], out_r = (float)v.f64[F_OUT][at(t, P.rev, Lall, RS, r)];
-    const float tt_l = v.f32[G_TT][at(t, l, L, RS, r)], tt_r = v.f32[G_TT][at(t, P.rev, L, RS, r)];
-    const float spd = q.obs_mode == 5 ? v.f32[G_V][at(t, l, L, RS, r)] : 0.0f;
-    const float dens = dens_at(v, P, l, t, r);
-    const float gate = (float)v.back[(size_t)l * RS + r];
-    if (live) {
-      float* oi = o + w * q.fpl;
-      switch (q.obs_mode) {
-        case 1: oi[0] = in_l; oi[1] = out_r; oi[2] = gate; break;
-        case 2: oi[0] = in_l; oi[1] = out_r; oi[2] = dens; oi[3] = gate; break;
-        case 3: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = gate; break;
-        case 4: oi[0] = dens / (float)P.kj; oi[1] = gate; break;
-        default: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = spd; oi[5] = dens; oi[6] = gate;
-      }
-      if (q.normalize) {  // builders.py:204-238, applied literally
-        if (q.obs_mode == 1 || q.obs_mode == 2) { oi[0] = oi[0] / 20.0f; oi[1] = oi[1] / 20.0f; }
-        else if (q.obs_mode == 3) { oi[0] = oi[0] / 6.0f; oi[1] = oi[1] / 20.0f; oi[2] = oi[2] / 20.0f; }
-      }
-    }
-    sT[w][lane] = tt_l + tt_r;  // T_ell + T_ell_reverse, float32 (pz_pednet_env.py:566)
-    sD[w][lane] = dens;
-    sKc[w][lane] = (float)P.kc;
-  }
-  __syncthreads();
-  if (w == 0 && live) {
-    float reward = 0.0f;
-    bool rewarded = false;
-    if (type == 1) {  // reward terms in link order, float32 throughout (pz_pednet_env.py:557-577)
-      float lr = 0.0f, dens_sum = 0.0f;
-      for (int i = 0; i < n; ++i) {
-        const float d = sD[i][lane];
-        lr = (i == 0) ? 0.0f - sT[i][lane] : lr - sT[i][lane];
-        if (d > 4.0f) lr = lr - 10.0f * (d - sKc[i][lane]);
-        dens_sum = (i == 0) ? d : dens_sum + d;
-      }
-      if (n > 1) {  // np.mean of float32: sequential float32 sum / n
-        const float avg = dens_sum / (float)n;
-        float dsum = 0.0f;
-        for (int i = 0; i < n; ++i) { const float d = fabsf(sD[i][lane] - avg); dsum = (i == 0) ? d : dsum + d; }
-        lr = lr - 10.0f * (dsum / (float)n);
-      }
-      reward = lr;
-      rewarded = true;
-    }
-    if (q.reward_mode == 0 && ag != 0) rewarded = false;  // the reference returns after the first agent (:581)
-    float* rw = q.rew + (size_t)r * q.n_agents + ag;
-    const float add = rewarded ? reward : 0.0f;
-    *rw = (accumulate && rewarded) ? *rw + add : (accumulate ? *rw : add);
-  }
-}
-
-// ---- state initialisation / host <-> device helpers ---------------------------------------------------------
-__global__ void init_state_kernel(DevView v) {
-  const int RS = v.RS, L = v.L, T1 = v.T1;
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)T1 * L * RS;
-  if (gid >= total) return;
-  int r = (int)(gid % RS);
-  int l = (int)((gid / RS) % L);
-  int t = (int)(gid / ((size_t)RS * L));
-  const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
-  v.f64[F_S][gid] = -1.0;
-  v.f64[F_R][gid] = -1.0;
-  v.f64[F_GATE][gid] = P.width;  // link.py:56
-  v.f32[G_TT][gid] = t == 0 ? P.tt0 : 0.0f;
-  v.f32[G_ATT][gid] = t < v.W ? P.tt0 : 0.0f;  // link.py:91
-  v.f32[G_N][gid] = 0.0f;
-  v.f32[G_K][gid] = 0.0f;
-  v.f32[G_V][gid] = 0.0f;
-  v.f32[G_LF][gid] = 0.0f;
-  if (t == 0) v.rsum[(size_t)l * RS + r] = P.tt0;  // link.py:84
-}
-
-template <typename T>
-__global__ void gather_kernel(const T* src, T* dst, int t0, int nt, int c0, int nc, int r0, int nr, int cols, int RS) {
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)nt * nc * nr;
-  if (gid >= total) return;
-  int r = (int)(gid % nr);
-  int c = (int)((gid / nr) % nc);
-  int t = (int)(gid / ((size_t)nr * nc));
-  dst[gid] = src[((size_t)(t0 + t) * cols + (c0 + c)) * RS + (r0 + r)];
-}
-
-// dst[(row0 + i) * RS + r] = src[i * src_stride + (per_replica ? r : 0)] for r in [r0, r1)
-__global__ void scatter_rows_kernel(double* dst, const double* src, int n_rows, size_t row0, size_t row_stride, int RS, int r0,
-                                    int r1, int per_replica, int src_stride) {
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int nr = r1 - r0;
-  if (gid >= (size_t)n_rows * nr) return;
-  int i = (int)(gid / nr);
-  int r = r0 + (int)(gid % nr);
-  dst[(row0 + (size_t)i * row_stride) * RS + r] = src[(size_t)i * src_stride + (per_replica ? r : 0)];
-}
-
-__global__ void device_math_kernel(int op, int n, const double* a, const double* b, uint32_t k0, uint32_t k1, double* out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double x = a[i], y = b ? b[i] : 0.0;
-  RngKey key{k0, k1, (uint32_t)i, 7u, 11u, 0u};
-  switch (op) {
-    case 0: out[i] = (double)pedn_powf((float)x, (float)y); break;
-    case 1: out[i] = pedn_exp(x); break;
-    case 2: out[i] = sqrt(x); break;
-    case 3: out[i] = x / y; break;
-    case 4: out[i] = (double)((float)x / (float)y); break;
-    case 5: out[i] = rng_binomial((long long)x, y, key, 0); break;
-    case 6: key.site = 3u; out[i] = x * rng_z(key); break;
-    case 7: out[i] = x + y; break;  // streaming calibration: 16 B read + 8 B written per lane, 8-byte accesses
-    default: out[i] = 0.0;
-  }
-}
+#include "pedn_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------- host side
 static thread_local std::string g_last_error;
