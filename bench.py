@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on one GPU)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--rng-mode", default="philox", choices=["philox", "meanfield"], help="diagnostic: meanfield removes the RNG work")
     ap.add_argument("--rl", action="store_true", help="config #5 instead: batched RL env step, env-steps/s")
     args = ap.parse_args()
     if args.rl:
@@ -170,7 +171,7 @@ def main():
     assert count == R
     gen = NetworkEnvGenerator(os.path.join(ROOT, "data"))
     net = gen.create_network(args.network, verbose=False, n_replicas=R, replica_offset=offset, rng_seed=0,
-                             device=local_rank)
+                             rng_mode=args.rng_mode, device=local_rank)
     T = net.simulation_steps
     e = net.engine()
     origins = list(net.origin_nodes)

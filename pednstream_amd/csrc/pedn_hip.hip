@@ -274,19 +274,27 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       if (e < 0 || e >= m->n_ent || ent_pair[e] != -1) { pedn_destroy(s); return fail(nullptr, PEDN_E_ARG, "pair_ent is not injective"); }
       ent_pair[e] = q;
     }
-    TRY(upload(s, ent_pair.data(), ent_pair.size(), &v.ent_pair));
     // exp(x)/exp(x) == 1 exactly as long as exp(x) is finite and non-zero; |x| <= temp * (|alpha| + |beta|*k_max/8 + |omega| + |eps|)
     const double xmax = fabs(m->pf_temp) * (fabs(m->pf_alpha) + fabs(m->pf_beta) * 16.0 + fabs(m->pf_omega) + fabs(m->pf_eps));
     const bool shortcut = xmax < 600.0;
-    std::vector<EntS> ents(std::max(m->n_ent, 1));
-    std::vector<int32_t> multi, pconst(std::max(m->n_pair, 1), 0);
+    std::vector<GrpRec> multi;
+    std::vector<int32_t> pconst(std::max(m->n_pair, 1), 0);
     for (int g = 0; g < m->n_grp; ++g) {
       const int a = m->grp_ent_ptr[g], b = m->grp_ent_ptr[g + 1];
       double sumd = 0.0;
       for (int e = a; e < b; ++e) sumd = (e == a) ? m->ent_dist[e] : sumd + m->ent_dist[e];
+      if (b - a == 1 && shortcut) {
+        if (ent_pair[a] >= 0) pconst[ent_pair[a]] = 1;
+        continue;
+      }
+      if (b - a < 1) continue;
+      GrpRec G{};
+      G.n = b - a;
+      G.allphys = m->grp_allphys[g];
       for (int e = a; e < b; ++e) {
-        EntS& E = ents[e];
+        GrpEnt& E = G.e[e - a];
         E.link = m->ent_link[e];
+        E.pair = ent_pair[e];
         E.rev = E.sep = 0; E.area32 = 1.0f; E.vf = E.kc = 0.0;
         if (E.link >= 0) {
           if (E.link >= L) { pedn_destroy(s); return fail(nullptr, PEDN_E_ARG, "ent_link out of range"); }
@@ -296,13 +304,15 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         }
         E.dist_term = (m->pf_alpha * m->ent_dist[e]) / (sumd + 1e-6);
       }
-      if (b - a == 1 && shortcut) { if (ent_pair[a] >= 0) pconst[ent_pair[a]] = 1; }
-      else if (b - a >= 1) multi.push_back(g);
+      multi.push_back(G);
     }
     v.n_multi = (int)multi.size();
-    TRY(upload(s, ents.data(), ents.size(), &v.ents));
-    TRY(upload(s, multi.data(), multi.size(), &v.grp_multi));
-    TRY(upload(s, pconst.data(), pconst.size(), &v.pair_const));
+    TRY(upload(s, multi.data(), multi.size(), &v.grp_rec));
+    {  // constant products read the shared row of ones (row n_pair of ent_p) instead of a row of their own
+      std::vector<int32_t> prow(std::max(m->n_pair, 1), 0);
+      for (int q = 0; q < m->n_pair; ++q) prow[q] = pconst[q] ? m->n_pair : q;
+      TRY(upload(s, prow.data(), prow.size(), &v.pair_row));
+    }
     s->h_pair_const = pconst;
     s->h_turn_pair_ptr.assign(m->turn_pair_ptr, m->turn_pair_ptr + m->n_turns + 1);
     s->h_turn_mode.assign(std::max(m->n_turns, 1), 0);
@@ -311,12 +321,11 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       for (int q = m->turn_pair_ptr[tn]; q < m->turn_pair_ptr[tn + 1]; ++q) all_const = all_const && pconst[q];
       s->h_turn_mode[tn] = all_const ? 1 : 0;
     }
-    TRY(upload(s, s->h_turn_mode.data(), s->h_turn_mode.size(), &v.turn_mode));
+    std::vector<TurnRec> trec(std::max(m->n_turns, 1));
+    for (int tn = 0; tn < m->n_turns; ++tn) trec[tn] = TurnRec{m->turn_pair_ptr[tn], m->turn_pair_ptr[tn + 1], s->h_turn_mode[tn], 0};
+    TRY(upload(s, trec.data(), trec.size(), &v.turn_rec));
     v.n_turns = m->n_turns;
   }
-  TRY(upload(s, m->grp_ent_ptr, m->n_grp + 1, &v.grp_ent_ptr));
-  TRY(upload(s, m->grp_allphys, m->n_grp, &v.grp_allphys));
-  TRY(upload(s, m->turn_pair_ptr, m->n_turns + 1, &v.turn_pair_ptr));
   TRY(upload(s, m->od_w, (size_t)m->n_od * v.T1, &v.od_w));
   {  // corridors: one lane of link_kernel updates both directions
     std::vector<CorrRec> cr;
@@ -329,11 +338,26 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     v.n_pairs_corr = (int)cr.size();
     TRY(upload(s, cr.data(), cr.size(), &v.corr_rec));
   }
-  {  // bin nodes into blocks of 8 waves (first-fit decreasing on the slot count)
-    std::vector<int> order(N);
+  {  // bin nodes into blocks of 8 waves: first-fit over the nodes ordered by (row-sum length, slot count) decreasing.
+    // The 8 waves of a block meet at two barriers, so a block lasts as long as its slowest wave; the slow waves are the
+    // rows of dynamic nodes that sum many (turn, od) products one dependent load after the other.  Packing those nodes
+    // into the same (and the first-launched) blocks keeps every other block short.
+    std::vector<int> order(N), cost(N, 0);
     for (int n = 0; n < N; ++n) order[n] = n;
     auto deg = [&](int n) { return m->node_slot_ptr[n + 1] - m->node_slot_ptr[n]; };
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return deg(a) > deg(b); });
+    for (int n = 0; n < N; ++n) {
+      if (m->node_kind[n] != 1 || !m->node_dyn[n]) continue;
+      const int d = deg(n);
+      for (int k = 0; k < d; ++k) {
+        int iters = 0;
+        for (int j = 0; j < d - 1; ++j) {
+          const int tn = m->node_turn_ptr[n] + k * (d - 1) + j;
+          if (!s->h_turn_mode[tn]) iters += (m->turn_pair_ptr[tn + 1] - m->turn_pair_ptr[tn] + 3) / 4;
+        }
+        cost[n] = std::max(cost[n], iters);
+      }
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] != cost[b] ? cost[a] > cost[b] : deg(a) > deg(b); });
     std::vector<std::vector<int>> bins;
     std::vector<int> fill;
     for (int n : order) {
@@ -381,7 +405,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     HIP_TRY(s, hipMemset(v.sepnp, 0, std::max<size_t>((size_t)L * RS, 1) * sizeof(double)));
     TRY(dalloc(s, (size_t)m->n_turns * RS, &v.tf));
     TRY(dalloc(s, (size_t)m->n_demand * T1 * RS, &v.demand));
-    TRY(dalloc(s, (size_t)std::max(m->n_pair, m->n_ent) * RS, &v.ent_p));
+    TRY(dalloc(s, ((size_t)m->n_pair + 1) * RS, &v.ent_p));  // [n_pair] probabilities + the row of ones
     TRY(dalloc(s, (size_t)m->n_pair * T1, &s->d_pair_pod));
     v.pair_pod = s->d_pair_pod;
     TRY(dalloc(s, (size_t)std::max(m->n_turns, 1) * T1, &s->d_turn_tab));
@@ -419,7 +443,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
                          (int)rows, (size_t)0, (size_t)1, v.RS, 0, v.RS, 0, 1);
       HIP_TRY(s, hipStreamSynchronize(s->stream));
     }
-    if (m->n_ent) HIP_TRY(s, hipMemsetAsync(v.ent_p, 0, (size_t)std::max(m->n_pair, m->n_ent) * v.RS * 8, s->stream));
+    if (m->n_pair) HIP_TRY(s, hipMemsetAsync(v.ent_p, 0, (size_t)m->n_pair * v.RS * 8, s->stream));  // not the row of ones
     // replica-uniform shortcuts: everything starts uniform; dynamic nodes always use their per-replica rows
     const double qnan = __builtin_nan("");
     s->h_front_u.assign(m->front_gate0, m->front_gate0 + L);

@@ -157,10 +157,9 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
   int gi = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
   int r = (int)(gid % (size_t)RS);
   if (gi >= v.n_multi) return;
-  const int g = v.grp_multi[gi];
+  const GrpRec& G = v.grp_rec[gi];  // wave-uniform: scalar loads
   uint32_t fl = 0;
-  const int a = v.grp_ent_ptr[g], n = v.grp_ent_ptr[g + 1] - a;
-  const int allphys = v.grp_allphys[g];
+  const int n = G.n, allphys = G.allphys;
   const int t2 = wrap_idx(t - 2, v.T1, fl);
   double cap[PEDN_MAX_DEGREE - 1];
   float kf[PEDN_MAX_DEGREE - 1];
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
 #pragma unroll
   for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
     if (e < n) {
-      const EntS E = v.ents[a + e];
+      const GrpEnt& E = G.e[e];
       if (E.link >= 0) {
         if (E.sep) kf[e] = v.f32[G_K][at(t - 1, E.link, v.L, RS, r)];  // Separator.get_density, link.py:427-428
         else kf[e] = (v.f32[G_N][at(t - 1, E.link, v.L, RS, r)] + v.f32[G_N][at(t - 1, E.rev, v.L, RS, r)]) / E.area32;
@@ -200,7 +199,7 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
         if (!(x > 0.0)) x = 0.0;
         nd = v.pf_beta * (x / 8.0);
       }
-      double u = v.ents[a + e].dist_term + nd - (v.pf_omega * cap[e]) / (sumc + 1e-6) + v.pf_eps;
+      double u = G.e[e].dist_term + nd - (v.pf_omega * cap[e]) / (sumc + 1e-6) + v.pf_eps;
       ex[e] = pedn_exp(-v.pf_temp * u);
       esum = (e == 0) ? ex[e] : esum + ex[e];
     }
@@ -208,7 +207,7 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
 #pragma unroll
   for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
     if (e < n) {
-      const int q = v.ent_pair[a + e];  // slot of the (turn, od) product that consumes this probability
+      const int q = G.e[e].pair;  // slot of the (turn, od) product that consumes this probability
       if (q >= 0) v.ent_p[(size_t)q * RS + r] = ex[e] / esum;
     }
   }
@@ -296,48 +295,56 @@ __global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
     if (kind == 1) {
       // turning fractions of row `slot`: static, or recomputed from the route-choice tables (path_finder.py:591-715)
       if (W.dyn) {
-        // tf[turn] = sum over the turn's (od) products P(down | up, od) * P(od | up)   (path_finder.py:668-686).
-        // The products of one row are contiguous: probabilities were stored in pair order by turn_prob_kernel and
-        // P(od | up) (replica independent, :599-615) was tabulated per pair and step on the host.
+        // tf[turn] = sum over the turn's (od) products P(down | up, od) * P(od | up)   (path_finder.py:668-686), in the
+        // reference's order.  P(od | up) is replica independent (:599-615) and tabulated per product and step on the host;
+        // P(down | up, od) was stored in product order by turn_prob_kernel, constant ones share one row of ones.  Products
+        // are taken eight at a time: eight independent loads, then the eight dependent adds (a row of a busy junction sums
+        // up to ~50 products; one dependent load per add made such rows the slowest waves of the launch).  The row is kept
+        // in the wave's own row of the LDS tile, so the turn loop is a real loop.
         const double* pod = v.pair_pod + (size_t)t * v.n_pair;
         const bool ppr = v.pod_pr != 0;  // per-replica OD weights: tables indexed [product][replica] instead of [step][product]
         double rowsum = 0.0;
+        for (int jj = 0; jj < m - 1; ++jj) {
+          const TurnRec T = v.turn_rec[turn0 + jj];
+          double acc = 0.0;
+          if (T.mode) {
+            acc = ppr ? v.turn_tab_r[(size_t)(turn0 + jj) * RS + r] : v.turn_tab[(size_t)t * v.n_turns + turn0 + jj];
+          } else {
+            for (int q = T.q0; q < T.q1; q += 8) {
+              double e[8], w[8];
 #pragma unroll
-        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
-          if (jj < m - 1) {
-            double acc = 0.0;
-            const int q1 = v.turn_mode[turn0 + jj] ? 0 : v.turn_pair_ptr[turn0 + jj + 1];
-            if (v.turn_mode[turn0 + jj]) acc = ppr ? v.turn_tab_r[(size_t)(turn0 + jj) * RS + r] : v.turn_tab[(size_t)t * v.n_turns + turn0 + jj];
-            for (int q = v.turn_pair_ptr[turn0 + jj]; q < q1; q += 4) {
-              // loads first (independent), then the strictly sequential sum the reference performs
-              double e0 = v.pair_const[q] ? 1.0 : v.ent_p[(size_t)q * RS + r];
-              double e1 = q + 1 < q1 ? (v.pair_const[q + 1] ? 1.0 : v.ent_p[(size_t)(q + 1) * RS + r]) : 0.0;
-              double e2 = q + 2 < q1 ? (v.pair_const[q + 2] ? 1.0 : v.ent_p[(size_t)(q + 2) * RS + r]) : 0.0;
-              double e3 = q + 3 < q1 ? (v.pair_const[q + 3] ? 1.0 : v.ent_p[(size_t)(q + 3) * RS + r]) : 0.0;
-              acc += e0 * (ppr ? v.pair_pod_r[(size_t)q * RS + r] : pod[q]);
-              if (q + 1 < q1) acc += e1 * (ppr ? v.pair_pod_r[(size_t)(q + 1) * RS + r] : pod[q + 1]);
-              if (q + 2 < q1) acc += e2 * (ppr ? v.pair_pod_r[(size_t)(q + 2) * RS + r] : pod[q + 2]);
-              if (q + 3 < q1) acc += e3 * (ppr ? v.pair_pod_r[(size_t)(q + 3) * RS + r] : pod[q + 3]);
+              for (int i = 0; i < 8; ++i) {
+                const int qi = q + i < T.q1 ? q + i : T.q1 - 1;  // past the end: re-read the last product, weight 0
+                e[i] = v.ent_p[(size_t)v.pair_row[qi] * RS + r];
+                w[i] = ppr ? v.pair_pod_r[(size_t)qi * RS + r] : pod[qi];
+              }
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const double term = q + i < T.q1 ? e[i] * w[i] : 0.0;  // acc + 0.0 == acc: acc is a sum of non-negative terms
+                acc += term;
+              }
             }
-            tfr[jj] = acc;
-            rowsum = (jj == 0) ? acc : rowsum + acc;
           }
+          const int j = jj < slot ? jj : jj + 1;
+          sPS[(size_t)(base + slot * m + j) * 64 + lane] = acc;
+          rowsum = (jj == 0) ? acc : rowsum + acc;
         }
         const bool renorm = fabs(rowsum - 1) > 1e-3;  // check_fractions, :700-714
+        for (int jj = 0; jj < m - 1; ++jj) {
+          const int j = jj < slot ? jj : jj + 1;
+          double f = sPS[(size_t)(base + slot * m + j) * 64 + lane];
+          if (renorm) f = rowsum > 1e-6 ? f / rowsum : 1.0 / (double)(m - 1);
+          v.tf[(size_t)(turn0 + jj) * RS + r] = f;
+          sPS[(size_t)(base + slot * m + j) * 64 + lane] = f * s_i;  // P[i][j] * s_i  (node.py:285)
+        }
+      } else {
+        // P[i][j] * s_i  (node.py:285)
 #pragma unroll
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
           if (jj < m - 1) {
-            if (renorm) tfr[jj] = rowsum > 1e-6 ? tfr[jj] / rowsum : 1.0 / (double)(m - 1);
-            v.tf[(size_t)(turn0 + jj) * RS + r] = tfr[jj];
+            const int j = jj < slot ? jj : jj + 1;
+            sPS[(size_t)(base + slot * m + j) * 64 + lane] = tfr[jj] * s_i;
           }
-        }
-      }
-      // P[i][j] * s_i  (node.py:285)
-#pragma unroll
-      for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
-        if (jj < m - 1) {
-          const int j = jj < slot ? jj : jj + 1;
-          sPS[(size_t)(base + slot * m + j) * 64 + lane] = tfr[jj] * s_i;
         }
       }
     } else {
@@ -669,6 +676,7 @@ __global__ void init_state_kernel(DevView v) {
   const int RS = v.RS, L = v.L, T1 = v.T1;
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)T1 * L * RS;
+  if (gid < (size_t)RS) v.ent_p[(size_t)v.n_pair * RS + gid] = 1.0;  // the row constant products read
   if (gid >= total) return;
   int r = (int)(gid % RS);
   int l = (int)((gid / RS) % L);

@@ -27,11 +27,24 @@ struct CorrRec {  // one lane group of link_kernel: both directions of a corrido
   LinkP Pa, Pb;
 };
 
-struct EntS {  // one downstream entry of a softmax group (update_node_turn_probs, path_finder.py:561-589)
+struct TurnRec {  // one turn of a dynamic node: its (turn, od) products and how its fraction is obtained
+  int32_t q0, q1;  // products [q0, q1) in the reference's summation order
+  int32_t mode;    // 1: every product is constant -> the raw fraction is tabulated per step on the host
+  int32_t pad;
+};
+
+struct GrpEnt {  // one downstream entry of a softmax group (update_node_turn_probs, path_finder.py:561-589)
   int32_t link, rev, sep;  // outgoing link (-1: virtual), its reverse, separator flag
+  int32_t pair;            // the (turn, od) product that consumes this entry's probability (-1: none)
   float area32;            // float32(length * width) of a plain link
+  int32_t pad;
   double vf, kc;           // for the capacity fallback back_gate * v_f * k_c * dt (:576)
   double dist_term;        // alpha * distance / (sum of the group's distances + 1e-6), static (:582)
+};
+
+struct GrpRec {  // one softmax group with more than one downstream: everything static a lane of turn_prob_kernel needs,
+  int32_t n, allphys, pad0, pad1;  // fetched by one scalar load burst at an address that depends on blockIdx only
+  GrpEnt e[PEDN_MAX_DEGREE - 1];
 };
 
 struct DevView {
@@ -55,11 +68,9 @@ struct DevView {
   const SlotRec* slot_rec;
   const CorrRec* corr_rec;
   const int32_t *node_kind, *node_slot_ptr, *node_turn_ptr, *node_demand_row, *node_dyn, *slot_in, *slot_out;
-  const int32_t *grp_ent_ptr, *grp_allphys, *ent_pair, *turn_pair_ptr;
-  const struct EntS* ents;      // static per-entry data of the softmax groups
-  const int32_t* grp_multi;     // groups with more than one downstream entry (single-entry groups have P = 1 exactly)
-  const int32_t* pair_const;    // [n_pair] 1: the product's probability is the constant 1
-  const int32_t* turn_mode;     // [n_turns] 1: every product of the turn is constant -> fraction tabulated per step on the host
+  const TurnRec* turn_rec;      // [n_turns]
+  const int32_t* pair_row;      // [n_pair] row of ent_p that holds the product's probability; constant products share the row of ones
+  const GrpRec* grp_rec;        // [n_multi] groups with more than one downstream entry (single-entry groups have P = 1 exactly)
   const double* turn_tab;       // [T+1][n_turns] tabulated raw fractions of such turns
   const double* pair_pod;  // [T+1][n_pair] P(od | up) of the pair's upstream group, replica independent
   int32_t L, Lall, T1, RS, R, W, n_grp, n_multi, n_pairs_corr, n_pair, n_turns;
