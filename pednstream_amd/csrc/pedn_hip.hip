@@ -30,6 +30,7 @@ struct pedn_sim {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int device = 0;
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
+  int node_waves = 6;  // register budget of node_kernel, see its comment
   std::vector<int32_t> node_turn_ptr, node_demand_row;
   std::vector<int32_t> h_up_od_ptr, h_upod_od, h_pair_upod;  // route-choice tables needed to re-tabulate P(od | up)
   std::vector<double> h_od_w;
@@ -352,7 +353,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         int iters = 0;
         for (int j = 0; j < d - 1; ++j) {
           const int tn = m->node_turn_ptr[n] + k * (d - 1) + j;
-          if (!s->h_turn_mode[tn]) iters += (m->turn_pair_ptr[tn + 1] - m->turn_pair_ptr[tn] + 3) / 4;
+          if (!s->h_turn_mode[tn]) iters += (m->turn_pair_ptr[tn + 1] - m->turn_pair_ptr[tn] + 7) / 8;
         }
         cost[n] = std::max(cost[n], iters);
       }
@@ -389,6 +390,13 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       }
     }
     s->n_blocks = (int)bins.size();
+    // latency-bound where many junctions sum route-choice products, throughput-bound otherwise (node_kernel comment).
+    // Measured at 6 / 8 waves: delft (989 non-constant products) 39.9 / 36.6 us, 45_intersections (42) 15.5 / 15.9,
+    // nine_intersections (66) 10.4 / 11.3, melbourne (0) 26.4 / 28.0.  PEDN_NODE_WAVES=6|8 overrides.
+    int nonconst = 0;
+    for (int q = 0; q < m->n_pair; ++q) nonconst += s->h_pair_const[q] ? 0 : 1;
+    s->node_waves = nonconst >= 256 ? 8 : 6;
+    if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = atoi(w) == 8 ? 8 : 6;
     TRY(upload(s, rec.data(), rec.size(), &v.slot_rec));
   }
   // ---- dynamic state
@@ -601,6 +609,12 @@ int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
   return PEDN_OK;
 }
 
+typedef void (*node_kernel_fn)(DevView, int);
+static node_kernel_fn node_kernel_for(const pedn_sim* s) {
+  if (s->v.pr) return s->node_waves == 8 ? node_kernel<true, 8> : node_kernel<true, 6>;
+  return s->node_waves == 8 ? node_kernel<false, 8> : node_kernel<false, 6>;
+}
+
 static int launch_step(pedn_sim* s, int t) {
   DevView& v = s->v;
   const unsigned rgroups = (unsigned)(v.RS / 64);
@@ -609,8 +623,7 @@ static int launch_step(pedn_sim* s, int t) {
     if (v.pr) hipLaunchKernelGGL(turn_prob_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
     else hipLaunchKernelGGL(turn_prob_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
   }
-  if (v.pr) hipLaunchKernelGGL(node_kernel<true>, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, v, t);
-  else hipLaunchKernelGGL(node_kernel<false>, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, v, t);
+  hipLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, v, t);
   if (v.n_pairs_corr > 0) {
     size_t n = (size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2);
     if (v.pr) hipLaunchKernelGGL(link_kernel_pr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
@@ -643,8 +656,7 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
     if (v.pr) hipExtLaunchKernelGGL(turn_prob_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
     else hipExtLaunchKernelGGL(turn_prob_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
   }
-  if (v.pr) hipExtLaunchKernelGGL(node_kernel<true>, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
-  else hipExtLaunchKernelGGL(node_kernel<false>, dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
+  hipExtLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
   if (v.n_pairs_corr > 0) {
     size_t n = (size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2);
     if (v.pr) hipExtLaunchKernelGGL(link_kernel_pr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[4], ev[5], 0, v, t);
@@ -961,3 +973,14 @@ int pedn_device_math(int32_t device, int32_t op, int32_t n, const double* a, con
 }
 
 }  // extern "C"
+
+#ifdef PEDN_PHASE_PROFILE
+// profiling build only (make phase-profile): read (zero = 0) or clear (zero = 1) the 16 phase accumulators of node_kernel
+extern "C" int pedn_debug_phases(unsigned long long* out, int zero) {
+  if (zero) {
+    unsigned long long z[16] = {0};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+  }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 16 * sizeof(unsigned long long));
+}
+#endif

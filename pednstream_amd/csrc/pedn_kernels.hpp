@@ -16,6 +16,15 @@
 
 using namespace pedn;
 
+// Optional wave-lifetime profile of node_kernel (make phase-profile -> libpedn_hip_phase.so, tools/phase_profile.py):
+// s_memtime stamps at the phase boundaries, summed over all waves into g_phase.  Not part of the product build.
+#ifdef PEDN_PHASE_PROFILE
+__device__ unsigned long long g_phase[16];
+#define PH(i, dep) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) : "v"(dep) : "memory"); ph[i] = _t; } while (0)
+#else
+#define PH(i, dep)
+#endif
+
 __device__ __forceinline__ size_t at(int t, int col, int cols, int RS, int r) {
   return ((size_t)t * (size_t)cols + (size_t)col) * (size_t)RS + (size_t)r;
 }
@@ -215,8 +224,11 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
 }
 
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
-template <bool PR>
-__global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
+// WAVES = waves per SIMD the register allocation aims at.  6: no spills, 3 blocks per CU -- best where the launch is bound by
+// HBM throughput (melbourne: 26.4 us against 28.0).  8: 64 VGPRs with 12 spilled, 4 blocks per CU -- best where it is bound by
+// latency, i.e. with dynamic junctions (delft: 36.6 us against 39.9).  pedn_create picks one per model.
+template <bool PR, int WAVES>
+__global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   __shared__ double sPS[64 * 64];  // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
   __shared__ double sR[8 * 64];    // receiving flow of each wave's outgoing link
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -226,9 +238,14 @@ __global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
   // of the same history rows
   const int r = (int)blockIdx.x * 64 + lane;
   const int tp = t - 1;
+#ifdef PEDN_PHASE_PROFILE
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  PH(0, lane);
+#endif
   const SlotRec& W = v.slot_rec[(size_t)blockIdx.y * 8 + wave];  // wave-uniform: scalar loads
   const int node = W.node, slot = W.slot, base = W.base, m = W.m;
   const bool active = node >= 0;
+  PH(1, lane + node);
   uint32_t fl = 0;
   double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0, co_prev = 0.0, ci_prev = 0.0;
   int lin = 0, lout = 0, kind = 0;
@@ -240,6 +257,52 @@ __global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
     lout = W.lout;
     const int turn0 = W.turn0 + slot * (m - 1);
     const bool static_tf = kind == 1 && !W.dyn;
+    // (called after the flows: run before them, next to the batch of history loads, the kernel took 67 us instead of 39 on
+    // delft x 1024 -- its waits drain the whole batch first)
+    auto dyn_row = [&]() {
+        // tf[turn] = sum over the turn's (od) products P(down | up, od) * P(od | up)   (path_finder.py:668-686), in the
+        // reference's order.  P(od | up) is replica independent (:599-615) and tabulated per product and step on the host;
+        // P(down | up, od) was stored in product order by turn_prob_kernel, constant ones share one row of ones.  Products
+        // are taken eight at a time: eight independent loads, then the eight dependent adds (a row of a busy junction sums
+        // up to ~50 products; one dependent load per add made such rows the slowest waves of the launch).  The row is kept
+        // in the wave's own row of the LDS tile, so the turn loop is a real loop.
+        const double* pod = v.pair_pod + (size_t)t * v.n_pair;
+        const bool ppr = v.pod_pr != 0;  // per-replica OD weights: tables indexed [product][replica] instead of [step][product]
+        double rowsum = 0.0;
+        for (int jj = 0; jj < m - 1; ++jj) {
+          const TurnRec T = v.turn_rec[turn0 + jj];
+          double acc = 0.0;
+          if (T.mode) {
+            acc = ppr ? v.turn_tab_r[(size_t)(turn0 + jj) * RS + r] : v.turn_tab[(size_t)t * v.n_turns + turn0 + jj];
+          } else {
+            for (int q = T.q0; q < T.q1; q += 8) {
+              double e[8], w[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const int qi = q + i < T.q1 ? q + i : T.q1 - 1;  // past the end: re-read the last product, weight 0
+                e[i] = v.ent_p[(size_t)v.pair_row[qi] * RS + r];
+                w[i] = ppr ? v.pair_pod_r[(size_t)qi * RS + r] : pod[qi];
+              }
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const double term = q + i < T.q1 ? e[i] * w[i] : 0.0;  // acc + 0.0 == acc: acc is a sum of non-negative terms
+                acc += term;
+              }
+            }
+          }
+          const int j = jj < slot ? jj : jj + 1;
+          sPS[(size_t)(base + slot * m + j) * 64 + lane] = acc;
+          rowsum = (jj == 0) ? acc : rowsum + acc;
+        }
+        const bool renorm = fabs(rowsum - 1) > 1e-3;  // check_fractions, :700-714
+        for (int jj = 0; jj < m - 1; ++jj) {
+          const int j = jj < slot ? jj : jj + 1;
+          double f = sPS[(size_t)(base + slot * m + j) * 64 + lane];
+          if (renorm) f = rowsum > 1e-6 ? f / rowsum : 1.0 / (double)(m - 1);
+          v.tf[(size_t)(turn0 + jj) * RS + r] = f;
+          sPS[(size_t)(base + slot * m + j) * 64 + lane] = f;
+        }
+    };
     if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
       s_i = v.demand[((size_t)W.demand_row * v.T1 + tp) * RS + r];
       co_prev = v.f64[F_CO][at(tp, lin, Lall, RS, r)];
@@ -284,10 +347,13 @@ __global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
       }
       co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
       ci_prev = x.ci_out;  // cumulative_inflow[t-1] of the outgoing link
+      PH(2, x.n_in + x.k_in + x.att_in + (float)(x.co_in + x.s_prev + x.co_sw + x.ci_out + x.r_prev + x.front_in + x.back_out));
       s_i = early ? 0.0 : send_flow(v, Pin, lin, tp, r, x, fl);
+      PH(3, s_i);
       v.f64[F_S][at(tp, lin, L, RS, r)] = s_i;  // link.py:268,367
       if (s_i < 0.0) fl |= PEDN_F_NEG_FLOW;
       r_i = recv_flow(v, Pout, lout, tp, r, x, s_i, fl);
+      PH(4, r_i);
       v.f64[F_R][at(tp, lout, L, RS, r)] = r_i;  // node.py:206
     }
     if (s_i < 0.0 || r_i < 0.0) fl |= PEDN_F_NEG_FLOW;
@@ -295,47 +361,10 @@ __global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
     if (kind == 1) {
       // turning fractions of row `slot`: static, or recomputed from the route-choice tables (path_finder.py:591-715)
       if (W.dyn) {
-        // tf[turn] = sum over the turn's (od) products P(down | up, od) * P(od | up)   (path_finder.py:668-686), in the
-        // reference's order.  P(od | up) is replica independent (:599-615) and tabulated per product and step on the host;
-        // P(down | up, od) was stored in product order by turn_prob_kernel, constant ones share one row of ones.  Products
-        // are taken eight at a time: eight independent loads, then the eight dependent adds (a row of a busy junction sums
-        // up to ~50 products; one dependent load per add made such rows the slowest waves of the launch).  The row is kept
-        // in the wave's own row of the LDS tile, so the turn loop is a real loop.
-        const double* pod = v.pair_pod + (size_t)t * v.n_pair;
-        const bool ppr = v.pod_pr != 0;  // per-replica OD weights: tables indexed [product][replica] instead of [step][product]
-        double rowsum = 0.0;
-        for (int jj = 0; jj < m - 1; ++jj) {
-          const TurnRec T = v.turn_rec[turn0 + jj];
-          double acc = 0.0;
-          if (T.mode) {
-            acc = ppr ? v.turn_tab_r[(size_t)(turn0 + jj) * RS + r] : v.turn_tab[(size_t)t * v.n_turns + turn0 + jj];
-          } else {
-            for (int q = T.q0; q < T.q1; q += 8) {
-              double e[8], w[8];
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const int qi = q + i < T.q1 ? q + i : T.q1 - 1;  // past the end: re-read the last product, weight 0
-                e[i] = v.ent_p[(size_t)v.pair_row[qi] * RS + r];
-                w[i] = ppr ? v.pair_pod_r[(size_t)qi * RS + r] : pod[qi];
-              }
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const double term = q + i < T.q1 ? e[i] * w[i] : 0.0;  // acc + 0.0 == acc: acc is a sum of non-negative terms
-                acc += term;
-              }
-            }
-          }
+        dyn_row();
+        for (int jj = 0; jj < m - 1; ++jj) {  // P[i][j] * s_i  (node.py:285)
           const int j = jj < slot ? jj : jj + 1;
-          sPS[(size_t)(base + slot * m + j) * 64 + lane] = acc;
-          rowsum = (jj == 0) ? acc : rowsum + acc;
-        }
-        const bool renorm = fabs(rowsum - 1) > 1e-3;  // check_fractions, :700-714
-        for (int jj = 0; jj < m - 1; ++jj) {
-          const int j = jj < slot ? jj : jj + 1;
-          double f = sPS[(size_t)(base + slot * m + j) * 64 + lane];
-          if (renorm) f = rowsum > 1e-6 ? f / rowsum : 1.0 / (double)(m - 1);
-          v.tf[(size_t)(turn0 + jj) * RS + r] = f;
-          sPS[(size_t)(base + slot * m + j) * 64 + lane] = f * s_i;  // P[i][j] * s_i  (node.py:285)
+          sPS[(size_t)(base + slot * m + j) * 64 + lane] *= s_i;
         }
       } else {
         // P[i][j] * s_i  (node.py:285)
@@ -352,7 +381,9 @@ __global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
     }
     sR[wave * 64 + lane] = r_i;
   }
+  PH(5, r_i);
   __syncthreads();
+  PH(6, lane);
 
   if (active && kind == 1) {
     // column `slot`: D_j = sum_i P[i][j] s_i (i ascending), g_ij = floor(min(P s, r_j * (P s / D_j)))  (node.py:286-298)
@@ -378,7 +409,9 @@ __global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
       }
     }
   }
+  PH(7, qi);
   __syncthreads();
+  PH(8, lane);
 
   if (active) {
     if (kind == 1) {
@@ -402,6 +435,15 @@ __global__ __launch_bounds__(512, 6) void node_kernel(DevView v, int t) {
     v.f64[F_CI][at(t, lout, Lall, RS, r)] = ci_prev + qi;
     if (fl) atomicOr(&v.flags[r], fl);
   }
+#ifdef PEDN_PHASE_PROFILE
+  PH(9, qo + qi);
+  if (active && lane == 0) {
+    for (int i = 1; i < 10; ++i) if (ph[i] == 0) ph[i] = ph[i - 1];
+    for (int i = 1; i < 10; ++i) atomicAdd(&g_phase[i], ph[i] - ph[i - 1]);
+    atomicAdd(&g_phase[10], 1ull);
+    atomicAdd(&g_phase[11], ph[9] - ph[0]);
+  }
+#endif
 }
 
 // BiDirectionalFd.__call__ + the travel-time part of Link.update_speeds for one direction and one replica; pure arithmetic

@@ -1,0 +1,53 @@
+"""Where the lifetime of a node_kernel wave goes: s_memtime stamps at the phase boundaries, summed over all waves.
+
+Needs the profiling build of the engine (`make -C pednstream_amd/csrc phase-profile`, adds ~10 % to the kernel) and a GPU:
+
+    python tools/phase_profile.py melbourne delft
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "pednstream_amd", "csrc", "libpedn_hip_phase.so")
+os.environ["PEDN_HIP_LIB"] = LIB
+
+from bench import replica_demand  # noqa: E402
+from pednstream_amd import NetworkEnvGenerator  # noqa: E402
+
+PHASES = ["kernel entry -> slot record", "slot record -> batch of history loads", "sending flow (look-backs, diffusion, binomial)",
+          "receiving flow", "turning-fraction row, P*s into LDS", "barrier 1 (slowest wave of the block)", "column pass",
+          "barrier 2", "row sums + stores"]
+
+
+def main():
+    lib = ctypes.CDLL(LIB)
+    for network in sys.argv[1:] or ["melbourne"]:
+        gen = NetworkEnvGenerator(os.path.join(ROOT, "data"))
+        R = 1024
+        net = gen.create_network(network, verbose=False, n_replicas=R, rng_seed=0)
+        e = net.engine()
+        for r in range(R):
+            for nid in net.origin_nodes:
+                e.set_demand(net.nodes[nid].index, replica_demand(net.simulation_steps, r), replica=r)
+        net._dirty_demand = set()
+        e.run(1, 150)
+        e.synchronize()
+        lib.pedn_debug_phases(None, 1)
+        e.run(150, 250)
+        e.synchronize()
+        out = (ctypes.c_ulonglong * 16)()
+        lib.pedn_debug_phases(out, 0)
+        o = np.array(out[:], dtype=np.float64)
+        n, total = o[10], o[11]
+        print(f"== {network} x {R}: {int(n / 100)} active waves per launch, mean wave lifetime {total / n:.0f} s_memtime ticks")
+        for i, name in enumerate(PHASES, start=1):
+            print(f"   {name:48s} {o[i] / n:9.0f} ticks  {100 * o[i] / total:5.1f} %")
+        net.close()
+
+
+if __name__ == "__main__":
+    main()
