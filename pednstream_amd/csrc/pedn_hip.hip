@@ -31,6 +31,9 @@ struct pedn_sim {
   int device = 0;
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
   int node_waves = 6;  // register budget of node_kernel, see its comment
+  int fuse_tp = 0;     // the link update and the next step's turn probabilities share one launch (launch_step)
+  int tp_ran = 0;      // launch_step launched the stand-alone turn_prob_kernel (pedn_profile_step)
+  int tp_ready = -1;   // step whose turn probabilities are in ent_p (written by link_turn_kernel of the step before), -1: none
   std::vector<int32_t> node_turn_ptr, node_demand_row;
   std::vector<int32_t> h_up_od_ptr, h_upod_od, h_pair_upod;  // route-choice tables needed to re-tabulate P(od | up)
   std::vector<double> h_od_w;
@@ -296,12 +299,12 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         GrpEnt& E = G.e[e - a];
         E.link = m->ent_link[e];
         E.pair = ent_pair[e];
-        E.rev = E.sep = 0; E.area32 = 1.0f; E.vf = E.kc = 0.0;
+        E.rev = E.sep = 0; E.area32 = 1.0f; E.vf = E.kc = 0.0; E.length = 1.0;
         if (E.link >= 0) {
           if (E.link >= L) { pedn_destroy(s); return fail(nullptr, PEDN_E_ARG, "ent_link out of range"); }
           E.rev = m->link_rev[E.link]; E.sep = m->link_sep[E.link];
           E.area32 = (float)(m->link_length[E.link] * m->link_width[E.link]);
-          E.vf = m->link_vf[E.link]; E.kc = m->link_kc[E.link];
+          E.vf = m->link_vf[E.link]; E.kc = m->link_kc[E.link]; E.length = m->link_length[E.link];
         }
         E.dist_term = (m->pf_alpha * m->ent_dist[e]) / (sumd + 1e-6);
       }
@@ -397,6 +400,11 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     for (int q = 0; q < m->n_pair; ++q) nonconst += s->h_pair_const[q] ? 0 : 1;
     s->node_waves = nonconst >= 256 ? 8 : 6;
     if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = atoi(w) == 8 ? 8 : 6;
+    // One launch for the link update of t and the turn probabilities of t+1 saves the fixed cost of a launch (45_intersections
+    // x 2048: 30.7 -> 26.5 us per step) but the fused probabilities re-derive num_pedestrians from the flows (48 instead of
+    // 16 bytes per entry): with many groups the separate launch is as fast (delft x 1024: 59.9 fused, 58.4 separate).
+    s->fuse_tp = (size_t)v.n_multi * v.RS <= (size_t)131072;
+    if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
     TRY(upload(s, rec.data(), rec.size(), &v.slot_rec));
   }
   // ---- dynamic state
@@ -494,6 +502,7 @@ int pedn_destroy(pedn_sim* s) {
 int pedn_reset(pedn_sim* s) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   HIP_TRY(s, hipSetDevice(s->device));
+  s->tp_ready = -1;
   return reset_state(s);
 }
 
@@ -563,6 +572,7 @@ int pedn_set_width(pedn_sim* s, int32_t which, int32_t link, int32_t replica, do
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (link < 0 || link >= s->v.L || which < 0 || which > 3) return fail(s, PEDN_E_ARG, "link or selector out of range");
   double* dst = which == PEDN_W_FRONT ? s->v.front : which == PEDN_W_BACK ? s->v.back : which == PEDN_W_SEP ? s->v.sepw : s->v.sepnp;
+  if (which == PEDN_W_BACK) s->tp_ready = -1;  // capacity fallback of the turn probabilities (path_finder.py:575-576)
   int rc = push_rows(s, dst, &value, 1, (size_t)link, 1, replica);
   if (rc != PEDN_OK || which > PEDN_W_BACK) return rc;
   (which == PEDN_W_FRONT ? s->h_front_u : s->h_back_u)[link] = replica == PEDN_ALL ? value : __builtin_nan("");
@@ -573,6 +583,7 @@ int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
   if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
   if (which < 0 || which > 3) return fail(s, PEDN_E_ARG, "selector out of range");
   DevView& v = s->v;
+  if (which == PEDN_W_BACK) s->tp_ready = -1;
   if (v.L == 0) return PEDN_OK;
   double* dst = which == PEDN_W_FRONT ? v.front : which == PEDN_W_BACK ? v.back : which == PEDN_W_SEP ? v.sepw : v.sepnp;
   HIP_TRY(s, hipSetDevice(s->device));
@@ -615,19 +626,32 @@ static node_kernel_fn node_kernel_for(const pedn_sim* s) {
   return s->node_waves == 8 ? node_kernel<false, 8> : node_kernel<false, 6>;
 }
 
-static int launch_step(pedn_sim* s, int t) {
+// One step = node_kernel(t), then the link update of t -- fused, for models with softmax groups, with the turn probabilities
+// of t+1.  ev != nullptr: per-launch start/stop events {turn_prob, node, link} for pedn_profile_step.
+static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr) {
   DevView& v = s->v;
   const unsigned rgroups = (unsigned)(v.RS / 64);
-  if (v.n_multi > 0) {
-    size_t n = (size_t)v.n_multi * v.RS;
-    if (v.pr) hipLaunchKernelGGL(turn_prob_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
-    else hipLaunchKernelGGL(turn_prob_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+  const bool groups = v.n_multi > 0, fused = groups && s->fuse_tp;
+  auto launch = [&](auto kernel, dim3 grid, dim3 block, int e, auto... args) {
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, s->stream, ev[e], ev[e + 1], 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, 0, s->stream, args...);
+  };
+  if (groups && s->tp_ready != t) {  // first step of an episode, a repeated or an out-of-order step
+    const unsigned nb = (unsigned)(((size_t)v.n_multi * v.RS + 255) / 256);
+    if (v.pr) launch(turn_prob_kernel<true>, dim3(nb), dim3(256), 0, v, t);
+    else launch(turn_prob_kernel<false>, dim3(nb), dim3(256), 0, v, t);
+    s->tp_ran = 1;
   }
-  hipLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, v, t);
-  if (v.n_pairs_corr > 0) {
-    size_t n = (size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2);
-    if (v.pr) hipLaunchKernelGGL(link_kernel_pr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
-    else hipLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, t);
+  launch(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 2, v, t);
+  const unsigned nlb = (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2) + 255) / 256);
+  if (fused) {
+    const unsigned ntb = (unsigned)(((size_t)v.n_multi * v.RS + 255) / 256);
+    if (v.pr) launch(link_turn_kernel<true>, dim3(nlb + ntb), dim3(256), 4, v, t, nlb);
+    else launch(link_turn_kernel<false>, dim3(nlb + ntb), dim3(256), 4, v, t, nlb);
+    s->tp_ready = t + 1;
+  } else if (v.n_pairs_corr > 0) {
+    if (v.pr) launch(link_kernel_pr, dim3(nlb), dim3(256), 4, v, t);
+    else launch(link_kernel, dim3(nlb), dim3(256), 4, v, t);
   }
   return PEDN_OK;
 }
@@ -650,24 +674,14 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   // not the enqueue-to-completion interval an ordinary hipEventRecord bracket would measure.
   hipEvent_t ev[6];
   for (int i = 0; i < 6; ++i) HIP_TRY(s, hipEventCreate(&ev[i]));
-  const unsigned rgroups = (unsigned)(v.RS / 64);
-  if (v.n_multi > 0) {
-    size_t n = (size_t)v.n_multi * v.RS;
-    if (v.pr) hipExtLaunchKernelGGL(turn_prob_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
-    else hipExtLaunchKernelGGL(turn_prob_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[0], ev[1], 0, v, t);
-  }
-  hipExtLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 0, s->stream, ev[2], ev[3], 0, v, t);
-  if (v.n_pairs_corr > 0) {
-    size_t n = (size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2);
-    if (v.pr) hipExtLaunchKernelGGL(link_kernel_pr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[4], ev[5], 0, v, t);
-    else hipExtLaunchKernelGGL(link_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, ev[4], ev[5], 0, v, t);
-  }
+  s->tp_ran = 0;
+  launch_step(s, t, ev);
   HIP_TRY(s, hipGetLastError());
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   ms[0] = ms[1] = ms[2] = 0.0f;
-  if (v.n_multi > 0) HIP_TRY(s, hipEventElapsedTime(&ms[0], ev[0], ev[1]));
+  if (s->tp_ran) HIP_TRY(s, hipEventElapsedTime(&ms[0], ev[0], ev[1]));  // stand-alone turn probabilities (normally fused into [2])
   HIP_TRY(s, hipEventElapsedTime(&ms[1], ev[2], ev[3]));
-  if (v.n_pairs_corr > 0) HIP_TRY(s, hipEventElapsedTime(&ms[2], ev[4], ev[5]));
+  if (v.n_pairs_corr > 0 || v.n_multi > 0) HIP_TRY(s, hipEventElapsedTime(&ms[2], ev[4], ev[5]));
   for (int i = 0; i < 6; ++i) hipEventDestroy(ev[i]);
   return PEDN_OK;
 }
@@ -756,6 +770,7 @@ int pedn_timer_end(pedn_sim* s, float* ms) {
 int pedn_set_link_params(pedn_sim* s, const double* kc, const double* kj, const double* vf, const int32_t* fft, const int32_t* tau_sw,
                          const float* tt0) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  s->tp_ready = -1;
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   DevView& v = s->v;

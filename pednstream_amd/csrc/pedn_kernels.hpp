@@ -157,12 +157,14 @@ __device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int
 }
 
 // ------------------------------------------------------------------------------------------------- kernels
-// P(down | up, od) for every softmax group with more than one downstream (update_node_turn_probs, path_finder.py:561-589).
-// A group with a single downstream has P = e/e = 1 exactly; those are constants and never recomputed.
-template <bool PR>
-__global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
+// P(down | up, od) of step t for every softmax group with more than one downstream (update_node_turn_probs,
+// path_finder.py:561-589).  A group with a single downstream has P = e/e = 1 exactly; those are constants, never recomputed.
+// One lane per (group, replica).  FUSED: the lane runs inside link_turn_kernel next to the link update of step t-1, which has
+// not stored num_pedestrians[t-1] / density[t-1] yet -- they are recomputed here from [t-2] and the flows of t-1 with the
+// arithmetic of the link update (link.py:133-136), so the two parts of that launch do not depend on each other.
+template <bool PR, bool FUSED>
+__device__ __forceinline__ void turn_prob_body(const DevView& v, int t, size_t gid) {
   const int RS = v.RS;
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int gi = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
   int r = (int)(gid % (size_t)RS);
   if (gi >= v.n_multi) return;
@@ -170,6 +172,11 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
   uint32_t fl = 0;
   const int n = G.n, allphys = G.allphys;
   const int t2 = wrap_idx(t - 2, v.T1, fl);
+  auto peds = [&](int l) -> float {  // num_pedestrians[t-1]
+    if (!FUSED) return v.f32[G_N][at(t - 1, l, v.L, RS, r)];
+    const double d = v.f64[F_IN][at(t - 1, l, v.Lall, RS, r)] - v.f64[F_OUT][at(t - 1, l, v.Lall, RS, r)];
+    return (float)((double)v.f32[G_N][at(t - 2, l, v.L, RS, r)] + d);
+  };
   double cap[PEDN_MAX_DEGREE - 1];
   float kf[PEDN_MAX_DEGREE - 1];
   double sumc = 0.0;
@@ -178,8 +185,14 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
     if (e < n) {
       const GrpEnt& E = G.e[e];
       if (E.link >= 0) {
-        if (E.sep) kf[e] = v.f32[G_K][at(t - 1, E.link, v.L, RS, r)];  // Separator.get_density, link.py:427-428
-        else kf[e] = (v.f32[G_N][at(t - 1, E.link, v.L, RS, r)] + v.f32[G_N][at(t - 1, E.rev, v.L, RS, r)]) / E.area32;
+        if (E.sep) {  // Separator.get_density = density[t-1], link.py:427-428
+          if (!FUSED) kf[e] = v.f32[G_K][at(t - 1, E.link, v.L, RS, r)];
+          else {
+            const float na = peds(E.link);
+            const double w = v.sepw[(size_t)E.link * RS + r];
+            kf[e] = v.sepnp[(size_t)E.link * RS + r] != 0.0 ? (float)((double)na / (E.length * w)) : na / (float)(E.length * w);
+          }
+        } else kf[e] = (peds(E.link) + peds(E.rev)) / E.area32;
         double c = v.f64[F_R][at(t2, E.link, v.L, RS, r)];
         if (!(c >= 0.0)) {
           const double vf = PR ? v.vf_r[(size_t)E.link * RS + r] : E.vf, kc = PR ? v.kc_r[(size_t)E.link * RS + r] : E.kc;
@@ -221,6 +234,12 @@ __global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
     }
   }
   if (fl) atomicOr(&v.flags[r], fl);
+}
+
+// stand-alone launch: first step of an episode, or a step that does not follow the previous one
+template <bool PR>
+__global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
+  turn_prob_body<PR, false>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
@@ -500,9 +519,8 @@ __device__ __forceinline__ void st2(float* p, size_t i, float a, float b) { *rei
 
 // Network.update_link_states (network.py:257-264).  One lane = both directions of one corridor for TWO adjacent replicas:
 // every history access is a 16-byte (f64) or 8-byte (f32) vector access, i.e. 1 KiB / 512 B per wave instruction.
-__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) {
+__device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
   const int RS = v.RS, L = v.L, Lall = v.Lall, H = RS / 2;
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)H));
   const int r = 2 * (int)(gid % (size_t)H);
   if (p >= v.n_pairs_corr) return;
@@ -565,9 +583,8 @@ __global__ __launch_bounds__(256) void link_kernel(DevView v, int t) {
 }
 
 // Same update with per-replica link parameters: one replica per lane (the parameters live in vector registers).
-__global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) {
+__device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid) {
   const int RS = v.RS, L = v.L, Lall = v.Lall;
-  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
   const int r = (int)(gid % (size_t)RS);
   if (p >= v.n_pairs_corr) return;
@@ -594,6 +611,23 @@ __global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) {
   v.rsum[(size_t)a * RS + r] = sa.rs; v.rsum[(size_t)b * RS + r] = sb.rs;
   if (ga != Pa.width) v.f64[F_GATE][at(t, a, L, RS, r)] = ga;
   if (gb != Pb.width) v.f64[F_GATE][at(t, b, L, RS, r)] = gb;
+}
+
+__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) { link_body(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
+__global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) { link_pr_body(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
+
+// Models with softmax groups: ONE launch after node_kernel(t) holds the link update of step t (blocks < n_link_blocks) and the
+// turn probabilities of step t+1 (the other blocks).  Both read only what node_kernel(t) and earlier launches wrote, so they
+// are independent; a separate turn-probability launch cost 6-9 us per step, most of it the fixed cost of a launch.
+template <bool PR>
+__global__ __launch_bounds__(256) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks) {
+  if (blockIdx.x < n_link_blocks) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (PR) link_pr_body(v, t, gid);
+    else link_body(v, t, gid);
+  } else {
+    turn_prob_body<PR, true>(v, t + 1, (size_t)(blockIdx.x - n_link_blocks) * blockDim.x + threadIdx.x);
+  }
 }
 
 // ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------

@@ -40,6 +40,7 @@ struct GrpEnt {  // one downstream entry of a softmax group (update_node_turn_pr
   int32_t pad;
   double vf, kc;           // for the capacity fallback back_gate * v_f * k_c * dt (:576)
   double dist_term;        // alpha * distance / (sum of the group's distances + 1e-6), static (:582)
+  double length;           // of the link (density of a separator = pedestrians / (length * separator width))
 };
 
 struct GrpRec {  // one softmax group with more than one downstream: everything static a lane of turn_prob_kernel needs,
