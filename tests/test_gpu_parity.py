@@ -159,6 +159,43 @@ def test_engine_equals_oracle_on_large_networks(name, replicas, steps):
     net.close()
 
 
+@pytest.mark.parametrize("name,steps", [("nine_intersections", 120), ("delft", 40), ("long_corridor", 150)])
+def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
+    """The engine picks its launch plan per model: turn probabilities of step t+1 fused into the link update of step t or
+    launched on their own (PEDN_FUSE_TP), node_kernel built for 6 or 8 waves per SIMD (PEDN_NODE_WAVES).  Every plan,
+    step-by-step stepping with a setter in between (which drops the fused probabilities) and a reset must give the same
+    bits in every field; the stand-alone launch is the one the goldens above pin for large models."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    def history(fuse, waves, stepwise):
+        monkeypatch.setenv("PEDN_FUSE_TP", fuse)
+        monkeypatch.setenv("PEDN_NODE_WAVES", waves)
+        np.random.seed(7)
+        net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=64, rng_seed=11)
+        if stepwise:
+            link = next(iter(net.links.values()))
+            for t in range(1, steps):
+                net.network_loading(t)
+                if t % 7 == 0:
+                    link.back_gate_width = link.back_gate_width     # same value: only invalidates the fused probabilities
+            net.engine().reset()                                      # second episode on the same engine
+            for t in range(1, steps):
+                net.network_loading(t)
+        else:
+            net.run(1, steps)
+        e = net.engine()
+        out = {f: e.read_block(LINK_FIELDS[f][0], 0, steps) for f in ALL_FIELDS}
+        net.close()
+        return out
+
+    ref = history("0", "6", False)
+    for fuse, waves, stepwise in (("1", "6", False), ("0", "8", False), ("1", "8", True)):
+        got = history(fuse, waves, stepwise)
+        for f in ALL_FIELDS:
+            assert np.array_equal(ref[f], got[f]), (fuse, waves, stepwise, f)
+
+
 def test_full_size_melbourne_1024_invariants():
     """BASELINE config at full size (melbourne x 1024): size-independent properties of the model
     (SURVEY section 4): cumulative = running sum of flows, pedestrian conservation, non-negativity,
