@@ -75,7 +75,7 @@ def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024):
     import glob
     if network != "melbourne" or replicas != 1024:
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:

@@ -992,10 +992,15 @@ int pedn_device_math(int32_t device, int32_t op, int32_t n, const double* a, con
 #ifdef PEDN_PHASE_PROFILE
 // profiling build only (make phase-profile): read (zero = 0) or clear (zero = 1) the 16 phase accumulators of node_kernel
 extern "C" int pedn_debug_phases(unsigned long long* out, int zero) {
-  if (zero) {
-    unsigned long long z[16] = {0};
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
-  }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 16 * sizeof(unsigned long long));
+  const size_t n = (size_t)PEDN_PHASE_WAVES * 12;
+  void* dev = nullptr;
+  if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_phase)) != hipSuccess) return -1;
+  if (zero) return (int)hipMemset(dev, 0, n * sizeof(unsigned long long));
+  std::vector<unsigned long long> h(n);
+  if (hipMemcpy(h.data(), dev, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  for (size_t w = 0; w < (size_t)PEDN_PHASE_WAVES; ++w)
+    for (int i = 0; i < 12; ++i) out[i] += h[w * 12 + i];
+  return 0;
 }
 #endif

@@ -19,7 +19,8 @@ using namespace pedn;
 // Optional wave-lifetime profile of node_kernel (make phase-profile -> libpedn_hip_phase.so, tools/phase_profile.py):
 // s_memtime stamps at the phase boundaries, summed over all waves into g_phase.  Not part of the product build.
 #ifdef PEDN_PHASE_PROFILE
-__device__ unsigned long long g_phase[16];
+#define PEDN_PHASE_WAVES (1 << 17)
+__device__ unsigned long long g_phase[PEDN_PHASE_WAVES * 12];  // [wave of the grid][phase]: plain stores, no contended atomics
 #define PH(i, dep) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) : "v"(dep) : "memory"); ph[i] = _t; } while (0)
 #else
 #define PH(i, dep)
@@ -458,9 +459,10 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   PH(9, qo + qi);
   if (active && lane == 0) {
     for (int i = 1; i < 10; ++i) if (ph[i] == 0) ph[i] = ph[i - 1];
-    for (int i = 1; i < 10; ++i) atomicAdd(&g_phase[i], ph[i] - ph[i - 1]);
-    atomicAdd(&g_phase[10], 1ull);
-    atomicAdd(&g_phase[11], ph[9] - ph[0]);
+    const size_t w = (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) % PEDN_PHASE_WAVES;
+    for (int i = 1; i < 10; ++i) g_phase[w * 12 + i] += ph[i] - ph[i - 1];
+    g_phase[w * 12 + 10] += 1ull;
+    g_phase[w * 12 + 11] += ph[9] - ph[0];
   }
 #endif
 }

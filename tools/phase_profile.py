@@ -7,6 +7,7 @@ Needs the profiling build of the engine (`make -C pednstream_amd/csrc phase-prof
 import ctypes
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -37,13 +38,16 @@ def main():
         e.run(1, 150)
         e.synchronize()
         lib.pedn_debug_phases(None, 1)
+        t0 = time.perf_counter()
         e.run(150, 250)
         e.synchronize()
+        wall = (time.perf_counter() - t0) / 100
         out = (ctypes.c_ulonglong * 16)()
         lib.pedn_debug_phases(out, 0)
         o = np.array(out[:], dtype=np.float64)
         n, total = o[10], o[11]
-        print(f"== {network} x {R}: {int(n / 100)} active waves per launch, mean wave lifetime {total / n:.0f} s_memtime ticks")
+        print(f"== {network} x {R}: {int(n / 100)} active waves per launch, mean wave lifetime {total / n:.0f} s_memtime ticks "
+              f"(instrumented step: {wall * 1e6:.1f} us)")
         for i, name in enumerate(PHASES, start=1):
             print(f"   {name:48s} {o[i] / n:9.0f} ticks  {100 * o[i] / total:5.1f} %")
         net.close()
