@@ -148,6 +148,10 @@ int pedn_destroy(pedn_sim* sim);
 
 /* values[n] -> demand[node][0..n-1] (rest zero); node is the model's node index, replica may be PEDN_ALL */
 int pedn_set_demand(pedn_sim* sim, int32_t node, int32_t replica, const double* values, int32_t n);
+/* demand[node][0..n-1] of one replica back to the host (what pedn_set_demand* / pedn_draw_demand left on the device) */
+int pedn_get_demand(pedn_sim* sim, int32_t node, int32_t replica, double* values, int32_t n);
+/* the same for every replica in one call: values[r * n + i] = demand of replica r at time index i (n <= T+1, rest zero) */
+int pedn_set_demand_matrix(pedn_sim* sim, int32_t node, const double* values, int32_t n);
 /* values[T+1] -> OD weight row `od` (shared by all replicas) */
 int pedn_set_od_weights(pedn_sim* sim, int32_t od, const double* values, int32_t n);
 int pedn_set_turning_fractions(pedn_sim* sim, int32_t node, int32_t replica, const double* tf, int32_t n);
@@ -233,6 +237,17 @@ int pedn_rl_step(pedn_sim* sim, const double* actions, int32_t on_device, int32_
                  float* rewards);
 /* device buffers for zero-copy consumers: 0 actions (f64 [R][n_actions]), 1 observations (f32 [R][n_obs]), 2 rewards (f32 [R][n_agents]) */
 void* pedn_rl_device_ptr(pedn_sim* sim, int32_t which);
+
+/* Origin demand drawn on the device for every replica at once -- the arrays DemandGenerator builds on the host
+ * (src/LTM/od_manager.py:92-155) for the patterns generate_random_demand_params picks (src/utils/env_loader.py:183-222):
+ *   pattern 0 gaussian_peaks: Poisson(base + peak * (bump(T/4) + bump(3T/4))), bump(c)(t) = exp(-(t-c)^2 / (2 (T/20)^2)), t < T
+ *   pattern 1 constant:       base for t <= T
+ *   pattern 2 sudden_demand:  pattern 0 plus `spike_height` for spike_start <= t < spike_start + spike_len
+ * Arrays are [n_replicas] for ONE origin node.  The Poisson draws are keyed (seed, global replica id, node, t) with
+ * Philox4x32-10 and inverted by sequential search; this is a generator of its own (same distributions as the reference,
+ * not numpy's stream) and is pinned by distribution tests only. */
+int pedn_draw_demand(pedn_sim* sim, int32_t node, uint64_t seed, const int32_t* pattern, const double* base, const double* peak,
+                     const int32_t* spike_start, const int32_t* spike_len, const double* spike_height);
 
 /* Diagnostic: evaluate the device-side arithmetic primitives on the GPU so that tests can compare them bit for bit
  * with the oracle.  op 0: powf(a[i], b[i]) -> out (f32 in a/b/out as doubles); 1: exp(a[i]); 2: sqrt(a[i]);

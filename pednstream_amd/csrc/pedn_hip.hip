@@ -534,6 +534,77 @@ int pedn_set_demand(pedn_sim* s, int32_t node, int32_t replica, const double* va
   return push_rows(s, s->v.demand, full.data(), s->v.T1, (size_t)row * s->v.T1, 1, replica);
 }
 
+int pedn_get_demand(pedn_sim* s, int32_t node, int32_t replica, double* values, int32_t n) {
+  if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
+  if (node < 0 || node >= s->n_nodes) return fail(s, PEDN_E_ARG, "node out of range");
+  const int row = s->node_demand_row[node];
+  if (row < 0) return fail(s, PEDN_E_ARG, "node has no virtual (origin/destination) link");
+  DevView& v = s->v;
+  if (replica < 0 || replica >= v.R) return fail(s, PEDN_E_ARG, "replica out of range");
+  if (n < 0 || n > v.T1) return fail(s, PEDN_E_ARG, "more values than time indices");
+  if (n == 0) return PEDN_OK;
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipMemcpy2D(values, 8, v.demand + (size_t)row * v.T1 * v.RS + replica, (size_t)v.RS * 8, 8, n, hipMemcpyDeviceToHost));
+  return PEDN_OK;
+}
+
+int pedn_set_demand_matrix(pedn_sim* s, int32_t node, const double* values, int32_t n) {
+  if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
+  if (node < 0 || node >= s->n_nodes) return fail(s, PEDN_E_ARG, "node out of range");
+  const int row = s->node_demand_row[node];
+  if (row < 0) return fail(s, PEDN_E_ARG, "node has no virtual (origin/destination) link");
+  DevView& v = s->v;
+  if (n < 0 || n > v.T1) return fail(s, PEDN_E_ARG, "more demand values than time indices");
+  if (n == 0) return PEDN_OK;
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));  // the staging buffer may still be read by an earlier scatter
+  const size_t bytes = (size_t)v.R * n * 8;
+  int rc = ensure_stage(s, bytes);
+  if (rc != PEDN_OK) return rc;
+  HIP_TRY(s, hipMemcpyAsync(s->stage, values, bytes, hipMemcpyHostToDevice, s->stream));
+  const size_t lanes = (size_t)v.T1 * v.RS;
+  hipLaunchKernelGGL(demand_matrix_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s->stream, v.demand, (const double*)s->stage,
+                     (size_t)row, n, v.T1, v.R, v.RS);
+  HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
+int pedn_draw_demand(pedn_sim* s, int32_t node, uint64_t seed, const int32_t* pattern, const double* base, const double* peak,
+                     const int32_t* spike_start, const int32_t* spike_len, const double* spike_height) {
+  if (!s || !pattern || !base || !peak || !spike_start || !spike_len || !spike_height) return fail(s, PEDN_E_ARG, "null argument");
+  if (node < 0 || node >= s->n_nodes) return fail(s, PEDN_E_ARG, "node out of range");
+  const int row = s->node_demand_row[node];
+  if (row < 0) return fail(s, PEDN_E_ARG, "node has no virtual (origin/destination) link");
+  DevView& v = s->v;
+  for (int r = 0; r < v.R; ++r) {
+    if (pattern[r] < 0 || pattern[r] > 2) return fail(s, PEDN_E_ARG, "demand pattern outside 0..2");
+    if (!(base[r] >= 0.0) || !(peak[r] >= 0.0) || base[r] + 2.0 * peak[r] > 500.0) return fail(s, PEDN_E_ARG, "demand rate outside [0, 500]");
+  }
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));  // the staging buffer may still be read by an earlier launch
+  // staging layout: pattern, spike_start, spike_len (int32 [R] each, padded to 8 bytes), then base, peak, spike_height (f64 [R])
+  const size_t R = (size_t)v.R, ioff = ((3 * R * 4 + 7) / 8) * 8, bytes = ioff + 3 * R * 8;
+  int rc = ensure_stage(s, bytes);
+  if (rc != PEDN_OK) return rc;
+  std::vector<unsigned char> h(bytes);
+  memcpy(h.data(), pattern, R * 4);
+  memcpy(h.data() + R * 4, spike_start, R * 4);
+  memcpy(h.data() + 2 * R * 4, spike_len, R * 4);
+  memcpy(h.data() + ioff, base, R * 8);
+  memcpy(h.data() + ioff + R * 8, peak, R * 8);
+  memcpy(h.data() + ioff + 2 * R * 8, spike_height, R * 8);
+  HIP_TRY(s, hipMemcpy(s->stage, h.data(), bytes, hipMemcpyHostToDevice));
+  const unsigned char* d = (const unsigned char*)s->stage;
+  const size_t lanes = (size_t)v.T1 * v.RS;
+  hipLaunchKernelGGL(draw_demand_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s->stream, v.demand, (size_t)row, v.T1, v.R,
+                     v.RS, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), v.replica_offset, (uint32_t)node,
+                     (const int32_t*)d, (const double*)(d + ioff), (const double*)(d + ioff + R * 8), (const int32_t*)(d + R * 4),
+                     (const int32_t*)(d + 2 * R * 4), (const double*)(d + ioff + 2 * R * 8));
+  HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
 int pedn_set_od_weights(pedn_sim* s, int32_t od, const double* values, int32_t n) {
   if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
   if (od < 0 || od >= s->n_od || n != s->v.T1) return fail(s, PEDN_E_ARG, "od index or length out of range");

@@ -794,6 +794,46 @@ __global__ void scatter_rows_kernel(double* dst, const double* src, int n_rows, 
   dst[(row0 + (size_t)i * row_stride) * RS + r] = src[(size_t)i * src_stride + (per_replica ? r : 0)];
 }
 
+// demand[row][t][r] = src[r][t] for t < n (0 beyond, and for the padding replicas): pedn_set_demand_matrix
+__global__ void demand_matrix_kernel(double* dst, const double* src, size_t row, int n, int T1, int R, int RS) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)T1 * RS) return;
+  const int t = (int)(gid / RS), r = (int)(gid % RS);
+  dst[(row * T1 + t) * RS + r] = (r < R && t < n) ? src[(size_t)r * n + t] : 0.0;
+}
+
+// pedn_draw_demand: one lane per (time index, replica) of one origin's demand row
+__global__ void draw_demand_kernel(double* dst, size_t row, int T1, int R, int RS, uint32_t k0, uint32_t k1, uint32_t replica_offset,
+                                   uint32_t node, const int32_t* pattern, const double* base, const double* peak,
+                                   const int32_t* spike_start, const int32_t* spike_len, const double* spike_height) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)T1 * RS) return;
+  const int t = (int)(gid / RS), r = (int)(gid % RS), T = T1 - 1;
+  double val = 0.0;
+  if (r < R) {
+    const int pat = pattern[r];
+    if (pat == 1) val = base[r];
+    else if (t < T) {
+      const double w = (double)T / 20.0, a = ((double)t - (double)T / 4.0), b = ((double)t - 3.0 * (double)T / 4.0);
+      const double lam = base[r] + peak[r] * exp(-(a * a) / (2.0 * w * w)) + peak[r] * exp(-(b * b) / (2.0 * w * w));
+      // Poisson(lam) by inversion: sequential search from 0 with one 53-bit uniform (lam stays below ~100 here)
+      uint32_t c[4] = {(uint32_t)t, node, 0x50u, replica_offset + (uint32_t)r};
+      philox4x32_10(c, k0, k1);
+      const double u = (double)((((uint64_t)c[0] << 32) | c[1]) >> 11) * 0x1p-53;
+      double p = exp(-lam), cdf = p;
+      int k = 0;
+      while (u > cdf && k < 1000) {
+        ++k;
+        p *= lam / (double)k;
+        cdf += p;
+      }
+      val = (double)k;
+      if (pat == 2 && t >= spike_start[r] && t < spike_start[r] + spike_len[r]) val += spike_height[r];
+    }
+  }
+  dst[(row * T1 + t) * RS + r] = val;
+}
+
 __global__ void device_math_kernel(int op, int n, const double* a, const double* b, uint32_t k0, uint32_t k1, double* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -97,6 +97,9 @@ def _load():
                                   C.POINTER(P)]),
         "pedn_destroy": (C.c_int, [P]),
         "pedn_set_demand": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
+        "pedn_set_demand_matrix": (C.c_int, [P, C.c_int32, _F64P, C.c_int32]),
+        "pedn_get_demand": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
+        "pedn_draw_demand": (C.c_int, [P, C.c_int32, C.c_uint64, _I32P, _F64P, _F64P, _I32P, _I32P, _F64P]),
         "pedn_set_od_weights": (C.c_int, [P, C.c_int32, _F64P, C.c_int32]),
         "pedn_set_turning_fractions": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
         "pedn_get_turning_fractions": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
@@ -141,7 +144,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand",
+EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand", "pedn_set_demand_matrix", "pedn_get_demand", "pedn_draw_demand",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
            "pedn_device_ptr", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_rl_configure",
@@ -200,6 +203,29 @@ class Engine:
     def set_demand(self, node_index, values, replica=None):
         v = np.ascontiguousarray(values, dtype=np.float64)
         self._ck(self._lib.pedn_set_demand(self._h, int(node_index), self._rep(replica), v.ctypes.data_as(_F64P), len(v)))
+
+    def get_demand(self, node_index, replica=0, n=None):
+        out = np.empty(self.T + 1 if n is None else int(n), dtype=np.float64)
+        self._ck(self._lib.pedn_get_demand(self._h, int(node_index), int(replica), out.ctypes.data_as(_F64P), len(out)))
+        return out
+
+    def set_demand_matrix(self, node_index, values):
+        """values [n_replicas, n]: the origin's demand of every replica in one upload."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.ndim != 2 or v.shape[0] != self.n_replicas:
+            raise ValueError(f"expected [n_replicas={self.n_replicas}, n], got {v.shape}")
+        self._ck(self._lib.pedn_set_demand_matrix(self._h, int(node_index), v.ctypes.data_as(_F64P), v.shape[1]))
+
+    def draw_demand(self, node_index, seed, pattern, base, peak, spike_start, spike_len, spike_height):
+        """Origin demand of every replica drawn on the device (include/pedn.h: pedn_draw_demand); arrays [n_replicas]."""
+        R = self.n_replicas
+        i32 = [np.ascontiguousarray(a, dtype=np.int32) for a in (pattern, spike_start, spike_len)]
+        f64 = [np.ascontiguousarray(a, dtype=np.float64) for a in (base, peak, spike_height)]
+        if any(a.shape != (R,) for a in i32 + f64):
+            raise ValueError(f"every argument must have shape [{R}]")
+        self._ck(self._lib.pedn_draw_demand(self._h, int(node_index), int(seed) & (2 ** 64 - 1), i32[0].ctypes.data_as(_I32P),
+                                            f64[0].ctypes.data_as(_F64P), f64[1].ctypes.data_as(_F64P), i32[1].ctypes.data_as(_I32P),
+                                            i32[2].ctypes.data_as(_I32P), f64[2].ctypes.data_as(_F64P)))
 
     def set_od_weights(self, od_index, values):
         v = np.ascontiguousarray(values, dtype=np.float64)

@@ -174,34 +174,44 @@ class VecPedNetEnv:
         self.sim_step = 1
 
     # ------------------------------------------------------------------------------------------------ API
-    def randomize(self, seed=None):
-        """Draw a new scenario for every env with the reference's randomisers (env_loader.py:183-259,363-424: link
-        parameters of 20 % of the corridors, OD weights, demand pattern / lambdas) and upload them per replica
-        (``pednstream_amd.scenarios``).  Two deliberate differences from ``randomize_network``: every env is perturbed from the
-        BASE configuration (the reference keeps perturbing its already perturbed config), and
-        ``generate_random_od_nodes`` is not applied because it changes the topology."""
+    def randomize(self, seed=None, mode="reference"):
+        """Draw a new scenario for every env and upload it per replica (``pednstream_amd.scenarios``).
+
+        ``mode="reference"``: the reference's randomisers, one np.random stream consumed env after env
+        (env_loader.py:183-259,363-424: link parameters of 20 % of the corridors, OD weights, demand pattern / lambdas) --
+        host-bound, ~0.25 ms per env.  ``mode="vectorised"``: the same distributions drawn for all envs at once, demand series
+        on the device (``ScenarioBatch.draw_random``); not the reference's random numbers.  Two deliberate differences from
+        ``randomize_network`` in both modes: every env is perturbed from the BASE configuration (the reference keeps
+        perturbing its already perturbed config), and ``generate_random_od_nodes`` is not applied because it changes the
+        topology."""
         from .scenarios import ScenarioBatch
 
         gen = self.env_generator
         if gen.config is None or gen.network_data is None:
             gen.network_data = gen.load_network_data(self.dataset)
-        if seed is not None:
-            np.random.seed(seed)
         batch = ScenarioBatch(self.network, edge_distances=gen.network_data["edge_distances"])
-        for r in range(self.n_envs):
-            batch.set_replica(r, link_params_overrides=gen.generate_random_link_params(None),
-                              od_flows=gen.generate_random_od_flows(None) if self.network.od_manager is not None else None,
-                              demand_params_overrides=gen.generate_random_demand_params(None))
+        if mode == "vectorised":
+            batch.draw_random(seed)
+        elif mode == "reference":
+            if seed is not None:
+                np.random.seed(seed)
+            for r in range(self.n_envs):
+                batch.set_replica(r, link_params_overrides=gen.generate_random_link_params(None),
+                                  od_flows=gen.generate_random_od_flows(None) if self.network.od_manager is not None else None,
+                                  demand_params_overrides=gen.generate_random_demand_params(None))
+        else:
+            raise ValueError(f"unknown randomisation mode {mode!r}")
         batch.commit(reset=False)
         self.scenarios = batch
 
     def reset(self, options=None, seed=None):
         """All replicas back to t = 0: histories cleared, widths back to their initial values.  ``options={'randomize':
-        True}`` additionally draws a new scenario per env (pz_pednet_env.py:143-193 rebuilds the network instead)."""
+        True}`` additionally draws a new scenario per env (pz_pednet_env.py:143-193 rebuilds the network instead);
+        ``'mode': 'vectorised'`` selects the batched generator (see ``randomize``)."""
         net = self.network
         eng = net.engine()
         if options and options.get("randomize", False):
-            self.randomize(seed)
+            self.randomize(seed, mode=options.get("mode", "reference"))
         eng.reset()
         net._init_dynamic_host_state()
         for which, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3)):

@@ -30,6 +30,16 @@ def derive_statics(length, vf, kc, kj, unit_time):
     return tt0, round(tt0 / unit_time), round(length / (shockwave_speed * unit_time))
 
 
+def derive_statics_arrays(length, vf, kc, kj, unit_time):
+    """``derive_statics`` for arrays (length [L, 1], the others [L, R]) with the same roundings: ``round`` of a float32 /
+    float64 quotient is round-half-even = ``np.rint``; ``np.float32 / unit_time`` is a float32 division (NEP 50)."""
+    shockwave_speed = (vf * kc) / (kj - kc)
+    tt0 = np.minimum(length / vf, length / 0.05).astype(np.float32)
+    fft = np.rint(tt0 / np.float32(unit_time)).astype(np.int32)
+    tau_sw = np.rint(length / (shockwave_speed * unit_time)).astype(np.int32)
+    return tt0, fft, tau_sw
+
+
 def merged_link_config(base_params, edge_distances, link_params_overrides):
     """``params['links']`` as create_network builds it (env_loader.py:93-144) from a base config and overrides."""
     links = copy.deepcopy(base_params.get("links", {}))
@@ -48,6 +58,11 @@ def merged_link_config(base_params, edge_distances, link_params_overrides):
     return links
 
 
+def _pair_of(link_id):
+    u, v = link_id.split("_")
+    return frozenset((int(u), int(v)))
+
+
 class ScenarioBatch:
     """Collects one scenario per replica for a ``Network`` and uploads them together."""
 
@@ -56,28 +71,41 @@ class ScenarioBatch:
         self.edge_distances = edge_distances
         L, R = network.n_links, network.n_replicas
         links = network._link_list
-        self.kc = np.repeat(np.array([[l.k_critical] for l in links], dtype=np.float64), R, axis=1)
-        self.kj = np.repeat(np.array([[l.k_jam] for l in links], dtype=np.float64), R, axis=1)
-        self.vf = np.repeat(np.array([[l.free_flow_speed] for l in links], dtype=np.float64), R, axis=1)
-        self.fft = np.repeat(np.array([[l.free_flow_tau] for l in links], dtype=np.int32), R, axis=1)
-        self.tau_sw = np.repeat(np.array([[l.tau_shockwave] for l in links], dtype=np.int32), R, axis=1)
-        self.tt0 = np.repeat(np.array([[l.travel_time0] for l in links], dtype=np.float32), R, axis=1)
+        base = {"kc": ("k_critical", np.float64), "kj": ("k_jam", np.float64), "vf": ("free_flow_speed", np.float64),
+                "fft": ("free_flow_tau", np.int32), "tau_sw": ("tau_shockwave", np.int32), "tt0": ("travel_time0", np.float32)}
+        self._base = {k: np.array([getattr(l, attr) for l in links], dtype=dt) for k, (attr, dt) in base.items()}
+        for k, col in self._base.items():
+            setattr(self, k, np.repeat(col[:, None], R, axis=1))
+        # an override of corridor "u_v" only changes the links between u and v (create_network merges link by link,
+        # env_loader.py:93-144): everything below works on the touched node pairs instead of the whole link table
+        self._pair_links, self._pair_edges = {}, {}
+        for l in links:
+            self._pair_links.setdefault(frozenset((l.start_node.node_id, l.end_node.node_id)), []).append(l)
+        for (u, v), d in (edge_distances or {}).items():        # dict order matters inside a pair
+            self._pair_edges.setdefault(frozenset((int(u), int(v))), []).append(((u, v), d))
         self.od_w = None
         if network.od_manager is not None:
-            base = network.od_manager.as_matrix()
-            self.od_w = np.repeat(base[:, :1], R, axis=1)
+            w0 = network.od_manager.as_matrix()
+            self.od_w = np.repeat(w0[:, :1], R, axis=1)
             self._od_index = {od: i for i, od in enumerate(network.od_manager.od_flows.keys())}
         self.demand = {}         # (node_id, replica) -> array
         self.link_params_dirty = self.od_dirty = False
 
-    def set_replica(self, r, link_params_overrides=None, od_flows=None, demand=None, demand_params_overrides=None):
-        """Scenario of replica ``r`` in the vocabulary of ``create_network``.  ``demand`` maps node id -> array and wins over
-        ``demand_params_overrides`` (which regenerates the origin demand with numpy's global RNG like the reference)."""
+    def _link_overrides(self, r, overrides):
         net = self.net
-        if link_params_overrides is not None:
-            cfg = merged_link_config(net.params, self.edge_distances, link_params_overrides)
-            default = net.params.get("default_link", {})
-            for link in net._link_list:
+        for k, col in self._base.items():        # the scenario of replica r starts from the base configuration
+            getattr(self, k)[:, r] = col
+        pairs = {_pair_of(link_id) for link_id in overrides}
+        edges = {}
+        for pr in pairs:
+            edges.update(dict(self._pair_edges.get(pr, [])))
+        sub = dict(net.params)
+        keys = {f"{a}_{b}" for pr in pairs for a in pr for b in pr if a != b}
+        sub["links"] = {k: v for k, v in net.params.get("links", {}).items() if k in keys}
+        cfg = merged_link_config(sub, edges if self.edge_distances else None, overrides)
+        default = net.params.get("default_link", {})
+        for pr in pairs:
+            for link in self._pair_links.get(pr, []):
                 i, j = link.start_node.node_id, link.end_node.node_id
                 a, b = (i, j) if i < j else (j, i)
                 lp = default
@@ -93,6 +121,13 @@ class ScenarioBatch:
                 k = link.index
                 self.kc[k, r], self.kj[k, r], self.vf[k, r] = kc, kj, vf
                 self.fft[k, r], self.tau_sw[k, r], self.tt0[k, r] = fft, tsw, tt0
+
+    def set_replica(self, r, link_params_overrides=None, od_flows=None, demand=None, demand_params_overrides=None):
+        """Scenario of replica ``r`` in the vocabulary of ``create_network``.  ``demand`` maps node id -> array and wins over
+        ``demand_params_overrides`` (which regenerates the origin demand with numpy's global RNG like the reference)."""
+        net = self.net
+        if link_params_overrides is not None:
+            self._link_overrides(r, link_params_overrides)
             self.link_params_dirty = True
         if od_flows is not None:
             if self.od_w is None:
@@ -104,8 +139,8 @@ class ScenarioBatch:
                 self.od_w[self._od_index[tuple(od)], r] = arr[0]
             self.od_dirty = True
         if demand_params_overrides is not None:
-            params = copy.deepcopy(net.params)
-            params.setdefault("demand", {})
+            params = dict(net.params)
+            params["demand"] = {k: dict(v) for k, v in net.params.get("demand", {}).items()}
             for key, ov in demand_params_overrides.items():
                 params["demand"].setdefault(key, {}).update(ov)
             gen = DemandGenerator(net.simulation_steps, params, None)
@@ -116,6 +151,60 @@ class ScenarioBatch:
         for nid, arr in (demand or {}).items():
             self.demand[(nid, r)] = np.asarray(arr, dtype=np.float64)
 
+    def draw_random(self, seed, link_fraction=0.2):
+        """A new scenario for EVERY replica, drawn for all replicas at once from the distributions of the reference's
+        randomisers: ``generate_random_link_params`` (env_loader.py:363-424: ``link_fraction`` of the corridors; with
+        probability 1/2 k_critical and k_jam scaled by U(0.6, 1.2) with the floors max(0.5, .) / max(2 k_c, .); with
+        probability 1/2 free_flow_speed scaled by U(0.6, 0.9)), ``generate_random_od_flows`` (:224-259: U(1, 10) per OD pair)
+        and ``generate_random_demand_params`` (:183-222: pattern, base U(2, 10), peak max(U(10, 30), base + 5)) with the demand
+        series of od_manager.py:92-112 drawn on the device (``pedn_draw_demand``).  One numpy Generator replaces the
+        reference's np.random stream per env, so this is the same distribution, not the same numbers -- for those use
+        ``set_replica`` with the mirrored ``generate_random_*``.  A perturbed corridor scales each of its links from that
+        link's own base parameters.  Uploads immediately; call ``commit`` for the reset."""
+        net = self.net
+        rng = np.random.default_rng(seed)
+        L, R = net.n_links, net.n_replicas
+        pairs = list(self._pair_links.keys())
+        P = len(pairs)
+        k = int(P * link_fraction)
+        if k > 0:
+            chosen = np.zeros((R, P), dtype=bool)
+            pick = np.argsort(rng.random((R, P)), axis=1)[:, :k]          # k corridors per replica without replacement
+            np.put_along_axis(chosen, pick, True, axis=1)
+            dens = chosen & (rng.random((R, P)) < 0.5)
+            f = rng.uniform(0.6, 1.2, (R, P))
+            spd = chosen & (rng.random((R, P)) < 0.5)
+            g = rng.uniform(0.6, 0.9, (R, P))
+            pair_of_link = np.empty(L, dtype=np.int64)
+            for p, pr in enumerate(pairs):
+                for l in self._pair_links[pr]:
+                    pair_of_link[l.index] = p
+            D, F = dens[:, pair_of_link].T, f[:, pair_of_link].T              # [L, R]
+            S, G = spd[:, pair_of_link].T, g[:, pair_of_link].T
+            kc0, kj0, vf0 = (self._base[n][:, None] for n in ("kc", "kj", "vf"))
+            self.kc = np.where(D, np.maximum(0.5, kc0 * F), kc0)
+            self.kj = np.where(D, np.maximum(self.kc * 2.0, kj0 * F), kj0)
+            self.vf = np.where(S, vf0 * G, vf0)
+            length = np.array([l.length for l in net._link_list], dtype=np.float64)[:, None]
+            self.tt0, self.fft, self.tau_sw = derive_statics_arrays(length, self.vf, self.kc, self.kj, net.unit_time)
+            self.link_params_dirty = True
+        if self.od_w is not None:
+            self.od_w = rng.uniform(1.0, 10.0, self.od_w.shape)
+            self.od_dirty = True
+        eng = net._flush()
+        T = net.simulation_steps
+        for node in net.nodes.values():
+            if node.virtual_incoming_link is None or node.node_id not in net.origin_nodes:
+                continue
+            pattern = rng.integers(0, 3, R)                                   # gaussian_peaks / constant / sudden_demand
+            base = rng.uniform(2.0, 10.0, R)
+            peak = np.maximum(rng.uniform(10.0, 30.0, R), base + 5.0)
+            spike_len = rng.integers(10, 20, R)
+            spike_start = rng.integers(0, np.maximum(1, T - spike_len))
+            spike_height = rng.integers(20, 50, R).astype(np.float64)
+            eng.draw_demand(node.index, int(rng.integers(0, 2 ** 63)), pattern, base, peak, spike_start, spike_len, spike_height)
+            self.demand = {key: v for key, v in self.demand.items() if key[0] != node.node_id}
+
     def commit(self, reset=True):
         """Upload everything that changed and (by default) reset the state: travel_time[0] depends on the parameters."""
         net = self.net
@@ -124,8 +213,20 @@ class ScenarioBatch:
             eng.set_link_params(self.kc, self.kj, self.vf, self.fft, self.tau_sw, self.tt0)
         if self.od_dirty:
             eng.set_od_weights_per_replica(self.od_w)
+        by_node = {}
         for (nid, r), arr in self.demand.items():
-            eng.set_demand(net.nodes[nid].index, arr, replica=r)
+            by_node.setdefault(nid, {})[r] = arr
+        R, T1 = net.n_replicas, net.simulation_steps + 1
+        for nid, rows in by_node.items():
+            if len(rows) == R and R > 1:        # every replica has its own array: one upload for the node
+                mat = np.zeros((R, T1))
+                for r, arr in rows.items():
+                    n = min(len(arr), T1)
+                    mat[r, :n] = arr[:n]
+                eng.set_demand_matrix(net.nodes[nid].index, mat)
+            else:
+                for r, arr in rows.items():
+                    eng.set_demand(net.nodes[nid].index, arr, replica=r)
         self.link_params_dirty = self.od_dirty = False
         self.demand = {}
         if reset:

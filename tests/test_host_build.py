@@ -120,3 +120,20 @@ def test_optimal_node_model_is_rejected():
     p = dict(g.info["params"], assign_flows_type="optimal")
     with pytest.raises(ValueError):
         Network(np.array(g.info["adjacency"]), p, origin_nodes=[0, 4], verbose=False)
+
+
+def test_array_statics_equal_the_scalar_expressions():
+    """derive_statics_arrays (batched scenario draws) == derive_statics (link.py:58-63,83-86,380) element by element."""
+    from pednstream_amd.scenarios import derive_statics, derive_statics_arrays
+
+    rng = np.random.default_rng(0)
+    for unit_time in (10, 5.0, 20):
+        L, R = 60, 20
+        length = rng.uniform(5, 400, (L, 1))
+        vf = rng.uniform(0.5, 1.6, (L, R))
+        kc = rng.uniform(0.5, 3, (L, R))
+        kj = kc * rng.uniform(2.0, 4.0, (L, R))
+        tt0, fft, tsw = derive_statics_arrays(length, vf, kc, kj, unit_time)
+        for i in range(L):
+            for j in range(R):
+                assert derive_statics(float(length[i, 0]), vf[i, j], kc[i, j], kj[i, j], unit_time) == (tt0[i, j], fft[i, j], tsw[i, j])
