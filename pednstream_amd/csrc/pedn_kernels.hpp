@@ -347,7 +347,9 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       const int t_sw = tp + 1 - Pout.tau_sw > 0 ? tp + 1 - Pout.tau_sw : 0;
       x.n_in = v.f32[G_N][at(tp, lin, L, RS, r)];
       x.n_out = v.f32[G_N][at(tp, lout, L, RS, r)];
-      x.k_in = v.f32[G_K][at(tp, lin, L, RS, r)];
+      // density[t'] of a plain link is num_pedestrians[t'] / float32(length * width) (link.py:136): recomputed from n_in with the
+      // link update's own division instead of being read back; a separator's density depends on its width at that time
+      x.k_in = Pin.sep ? v.f32[G_K][at(tp, lin, L, RS, r)] : 0.0f;
       x.att_in = v.f32[G_ATT][at(tp, lin, L, RS, r)];
       x.co_in = v.f64[F_CO][at(tp, lin, Lall, RS, r)];
       x.s_prev = v.f64[F_S][at(tm1, lin, L, RS, r)];
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
           if (jj < m - 1) tfr[jj] = shared ? v.tf_u[turn0 + jj] : v.tf[(size_t)(turn0 + jj) * RS + r];
       }
+      if (!Pin.sep) x.k_in = x.n_in / (float)(Pin.length * Pin.width);
       co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
       ci_prev = x.ci_out;  // cumulative_inflow[t-1] of the outgoing link
       PH(2, x.n_in + x.k_in + x.att_in + (float)(x.co_in + x.s_prev + x.co_sw + x.ci_out + x.r_prev + x.front_in + x.back_out));
