@@ -160,11 +160,12 @@ __device__ inline double rng_binomial(long long n, double p, const RngKey& k, in
   if (n <= 0 || p <= 0.0) return 0.0;
   if (meanfield) return floor((double)n * p);
   if (p >= 1.0) return (double)n;
+  // both branches start from Philox call 0: drawn once, ahead of the branch (lanes of one wave usually take both)
+  uint32_t w[4];
+  rng_words(k, 0u, w);
   if (n <= 16) {
     const uint32_t thr = (uint32_t)floor(p * 65536.0);
     const int nn = (int)n;
-    uint32_t w[4];
-    rng_words(k, 0u, w);
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -181,9 +182,11 @@ __device__ inline double rng_binomial(long long n, double p, const RngKey& k, in
     }
     return (double)cnt;
   }
+  const uint32_t hs = (w[0] & 0xffffu) + (w[0] >> 16) + (w[1] & 0xffffu) + (w[1] >> 16) + (w[2] & 0xffffu) + (w[2] >> 16) + (w[3] & 0xffffu) + (w[3] >> 16);
+  const double z = (double)((int)hs - 262140) * 0x1.3988e1409212ep-16;  // rng_z
   double mean = (double)n * p;
   double sd = sqrt(mean * (1.0 - p));
-  double x = floor(mean + sd * rng_z(k) + 0.5);
+  double x = floor(mean + sd * z + 0.5);
   if (x < 0.0) x = 0.0;
   if (x > (double)n) x = (double)n;
   return x;
