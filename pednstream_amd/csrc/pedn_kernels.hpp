@@ -840,6 +840,13 @@ __global__ void draw_demand_kernel(double* dst, size_t row, int T1, int R, int R
 __global__ void device_math_kernel(int op, int n, const double* a, const double* b, uint32_t k0, uint32_t k1, double* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (op == 8) {  // streaming calibration with 16-byte accesses: lane i < n/2 handles elements 2i, 2i+1 (n even)
+    if (2 * i + 1 < n) {
+      const double2 x2 = reinterpret_cast<const double2*>(a)[i], y2 = reinterpret_cast<const double2*>(b)[i];
+      reinterpret_cast<double2*>(out)[i] = make_double2(x2.x + y2.x, x2.y + y2.y);
+    }
+    return;
+  }
   double x = a[i], y = b ? b[i] : 0.0;
   RngKey key{k0, k1, (uint32_t)i, 7u, 11u, 0u};
   switch (op) {
