@@ -253,7 +253,8 @@ int pedn_draw_demand(pedn_sim* sim, int32_t node, uint64_t seed, const int32_t* 
  * with the oracle.  op 0: powf(a[i], b[i]) -> out (f32 in a/b/out as doubles); 1: exp(a[i]); 2: sqrt(a[i]);
  * 3: a[i]/b[i] (f64); 4: (float)a[i]/(float)b[i]; 5: binomial(n=a[i], p=b[i]) keyed (seed, replica=i, link=7, t=11,
  * site=0); 6: normal(sigma=a[i]) keyed (seed, replica=i, link=7, t=11); 7 / 8: a[i] + b[i] with 8- / 16-byte accesses
- * (streaming launches of known byte count for calibrating the HBM counters and the practical bandwidth ceiling). */
+ * (streaming launches of known byte count for calibrating the HBM counters and the practical bandwidth ceiling); 9: the same
+ * with chunks of `seed` doubles visited in a scrambled order (n and seed powers of two). */
 int pedn_device_math(int32_t device, int32_t op, int32_t n, const double* a, const double* b, uint64_t seed, double* out);
 
 #ifdef __cplusplus

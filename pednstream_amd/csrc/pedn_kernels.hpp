@@ -847,6 +847,13 @@ __global__ void device_math_kernel(int op, int n, const double* a, const double*
     }
     return;
   }
+  if (op == 9) {  // scattered-chunk calibration: chunks of k0 doubles visited in a scrambled order (n, k0 powers of two)
+    const uint32_t chunk = k0, nch = (uint32_t)n / chunk, c = (uint32_t)i / chunk;
+    const uint32_t pc = (c * 2654435761u + 12345u) & (nch - 1);  // odd multiplier: a permutation of the chunk ids
+    const size_t j = (size_t)pc * chunk + (uint32_t)i % chunk;
+    out[j] = a[j] + b[j];
+    return;
+  }
   double x = a[i], y = b ? b[i] : 0.0;
   RngKey key{k0, k1, (uint32_t)i, 7u, 11u, 0u};
   switch (op) {
