@@ -158,6 +158,41 @@ def test_vectorised_randomisation_draws_the_reference_ranges_for_every_env():
     env.close()
 
 
+@pytest.mark.parametrize("mode", ["reference", "vectorised"])
+def test_randomised_reset_is_a_function_of_the_seed(mode):
+    """Same seed -> the same scenarios, demand and trajectories (on a fresh env and on a reused one); another seed -> others."""
+    from pednstream_amd.rl_env import VecPedNetEnv
+
+    B, steps = 16, 30
+
+    def episode(env, seed):
+        obs0, _ = env.reset(options={"randomize": True, "mode": mode}, seed=seed)
+        sc = env.scenarios
+        e = env.network.engine()
+        origin = next(n for n in env.network.nodes.values() if n.virtual_incoming_link is not None and n.node_id in env.network.origin_nodes)
+        demand = np.stack([e.get_demand(origin.index, r) for r in range(B)])
+        rng = np.random.default_rng(1)
+        traj = [obs0.copy()]
+        for _ in range(steps):
+            obs, rew, *_ = env.step(rng.uniform(0, 4, size=(B, env.n_actions)))
+            traj.append(np.concatenate([obs.ravel(), rew.ravel()]))
+        return sc.kc.copy(), sc.vf.copy(), sc.od_w.copy(), demand, np.concatenate([t.ravel() for t in traj])
+
+    np.random.seed(0)
+    env = VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", data_dir=DATA, seed=9)
+    a = episode(env, 41)
+    b = episode(env, 42)
+    c = episode(env, 41)                         # the same env object, reused
+    np.random.seed(0)
+    env2 = VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", data_dir=DATA, seed=9)
+    d = episode(env2, 41)                        # a fresh env
+    for x, y, z in zip(a, c, d):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    assert not np.array_equal(a[3], b[3]) and not np.array_equal(a[4], b[4])
+    env.close()
+    env2.close()
+
+
 def test_multi_scenario_env_groups_have_their_own_topology():
     """randomize_network also moves OD nodes: every group is its own engine.  Group 0 under seed 3 is the scenario of golden
     randnet_i45_a (reference randomize_network('45_intersections', seed=3)); stepping with the widths untouched must
