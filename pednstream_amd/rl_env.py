@@ -254,6 +254,8 @@ class PedNetParallelEnv:
         self.possible_agents = list(self._vec.possible_agents)
         self.simulation_steps = self._vec.simulation_steps
         self._cumulative_rewards = {a: 0.0 for a in self.possible_agents}
+        self.render_mode = render_mode
+        self.dataset = dataset
 
     @property
     def agents(self):
@@ -280,10 +282,25 @@ class PedNetParallelEnv:
     def _dict(self, row):
         return {a: np.array(row[sl]) for a, sl in self._vec.obs_slices.items()}
 
+    def _infos(self):
+        """rl/pz_pednet_env.py:631-642"""
+        return {a: {"step": self.sim_step, "cumulative_reward": self._cumulative_rewards.get(a, 0.0)} for a in self.possible_agents}
+
+    def seed(self, seed):
+        """rl/pz_pednet_env.py:118-122: seeds the global generators the host-side randomisers draw from."""
+        import random
+
+        self._seed = seed
+        np.random.seed(seed)
+        random.seed(seed)
+
     def reset(self, seed=None, options=None):
-        obs, _ = self._vec.reset()
+        """``seed`` is ignored like in the reference (:143-193; it seeds at construction); ``options={'randomize': True}`` draws
+        a new scenario (link parameters, OD weights, demand -- not the OD nodes, see ``VecPedNetEnv.randomize``) from the
+        global np.random stream instead of rebuilding the network."""
+        obs, _ = self._vec.reset(options=options, seed=None)
         self._cumulative_rewards = {a: 0.0 for a in self.possible_agents}
-        return self._dict(obs[0]), {a: {} for a in self.possible_agents}
+        return self._dict(obs[0]), self._infos()
 
     def step(self, actions):
         for a in actions:
@@ -293,7 +310,6 @@ class PedNetParallelEnv:
         if len(actions) > 0:
             # agents without an action keep their current widths (apply_all_actions only touches the given agents)
             row = np.empty((1, self._vec.n_actions))
-            net = self.network
             for aid, sl in self._vec.action_slices.items():
                 if aid in actions:
                     row[0, sl] = np.asarray(actions[aid], dtype=np.float64).reshape(-1)
@@ -306,7 +322,19 @@ class PedNetParallelEnv:
         for a, r in rewards.items():
             self._cumulative_rewards[a] += r
         return (self._dict(obs[0]), rewards, {a: term for a in self.possible_agents},
-                {a: False for a in self.possible_agents}, {a: {} for a in self.possible_agents})
+                {a: False for a in self.possible_agents}, self._infos())
+
+    def save(self, simulation_dir, base_dir="../outputs"):
+        """rl/pz_pednet_env.py:688-691: the reference's JSON files, written from the device histories."""
+        from .output_handler import OutputHandler
+
+        OutputHandler(base_dir=base_dir, simulation_dir=simulation_dir).save_network_state(self.network)
+
+    def render(self, *a, **k):
+        """Plotting (NetworkVisualizer) is outside the hot path: nothing to do without a render mode, like the reference."""
+        if self.render_mode is None:
+            return None
+        raise NotImplementedError("rendering is not provided; save() writes the files the reference's visualiser reads")
 
     def close(self):
         self._vec.close()

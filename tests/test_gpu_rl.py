@@ -58,7 +58,7 @@ def test_many_envs_match_cpu_restatement():
     env.close()
 
 
-def test_single_env_facade_and_reset():
+def test_single_env_facade_and_reset(tmp_path):
     g = Golden("rl_nine_opt3")
     env = PedNetParallelEnv("nine_intersections", obs_mode="option3", seed=g.seed, network=build_network(g, n_replicas=1, replica_offset=g.replica, rng_seed=g.seed))
     acts, ref_obs, ref_rew = g.state("rl_actions"), g.state("rl_obs"), g.state("rl_rewards")
@@ -71,6 +71,7 @@ def test_single_env_facade_and_reset():
             flat = np.concatenate([obs[a] for a in env.possible_agents])
             assert np.array_equal(flat, ref_obs[k]) and np.array_equal(np.float32([rew[a] for a in env.possible_agents]), ref_rew[k])
             assert set(obs) == set(env.possible_agents) and not any(term.values())
+            assert all(info[a]["step"] == env.sim_step for a in env.possible_agents)          # pz_pednet_env.py:631-642
             out.append(flat)
         return out
 
@@ -86,6 +87,16 @@ def test_single_env_facade_and_reset():
     assert all(np.array_equal(a, b) for a, b in zip(first, second))
     with pytest.raises(ValueError):
         env.step({"gate_99": np.zeros(3)})
+    assert env.render() is None
+    total = {a: 0.0 for a in env.possible_agents}
+    env.reset()
+    for k in range(5):
+        _, rew, _, _, info = env.step({a: acts[k, sl] for a, sl in env._vec.action_slices.items()})
+        for a in total:
+            total[a] += rew[a]
+    assert all(info[a]["cumulative_reward"] == total[a] for a in total)
+    env.save("facade_save", base_dir=str(tmp_path))
+    assert sorted(p.name for p in (tmp_path / "facade_save").iterdir()) == ["link_data.json", "network_params.json", "node_data.json"]
     env.close()
 
 
