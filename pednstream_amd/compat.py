@@ -1,7 +1,8 @@
 """Drop-in aliases for the reference's import paths.
 
-The reference's callers import ``src.utils.env_loader.NetworkEnvGenerator``, ``src.LTM.network.Network`` and
-``src.utils.config.load_config`` (e.g. examples/six_node.py:8-10, rl/pz_pednet_env.py).  ``install()`` registers modules
+The reference's callers import ``src.utils.env_loader.NetworkEnvGenerator``, ``src.LTM.network.Network``,
+``src.utils.config.load_config``, ``handlers.output_handler.OutputHandler`` and ``rl.PedNetParallelEnv`` (e.g.
+examples/six_node.py:8-10, rl/rl_example.py).  ``install()`` registers modules
 of those names that resolve to this package, so such a script runs on the MI355X engine unchanged:
 
     import pednstream_amd.compat as compat; compat.install()
@@ -12,7 +13,7 @@ import types
 
 
 def install(force: bool = False):
-    from . import config, env_loader, network, od_manager, path_finder
+    from . import config, env_loader, network, od_manager, output_handler, path_finder, rl_env
 
     def mod(name, **attrs):
         if name in sys.modules and not force:
@@ -36,4 +37,11 @@ def install(force: bool = False):
     ltm.node = mod("src.LTM.node", Node=network.NodeView)
     utils.env_loader = mod("src.utils.env_loader", NetworkEnvGenerator=env_loader.NetworkEnvGenerator)
     utils.config = mod("src.utils.config", load_config=config.load_config, validate_config=config.validate_config)
+    # `from handlers.output_handler import OutputHandler` (examples/*.py) and `from rl import PedNetParallelEnv`
+    # (rl/rl_example.py, rl/train_*.py); the plotting module src.utils.visualizer is not provided
+    handlers = mod("handlers")
+    handlers.output_handler = mod("handlers.output_handler", OutputHandler=output_handler.OutputHandler)
+    rl = mod("rl", PedNetParallelEnv=rl_env.PedNetParallelEnv)
+    rl.pz_pednet_env = mod("rl.pz_pednet_env", PedNetParallelEnv=rl_env.PedNetParallelEnv)
+    rl.discovery = mod("rl.discovery", AgentManager=rl_env.AgentManager)
     return src

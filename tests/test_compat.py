@@ -8,7 +8,11 @@ compat.install()
 from src.utils.env_loader import NetworkEnvGenerator
 from src.LTM.network import Network
 from src.utils.config import load_config
-import pednstream_amd
+from handlers.output_handler import OutputHandler
+from rl import PedNetParallelEnv
+from rl.discovery import AgentManager
+import pednstream_amd, pednstream_amd.output_handler, pednstream_amd.rl_env
+assert OutputHandler is pednstream_amd.output_handler.OutputHandler and PedNetParallelEnv is pednstream_amd.rl_env.PedNetParallelEnv
 assert NetworkEnvGenerator is pednstream_amd.NetworkEnvGenerator and Network is pednstream_amd.Network
 gen = NetworkEnvGenerator("data")
 net = gen.create_network("od_flow_example", verbose=False)
