@@ -29,6 +29,12 @@ __device__ unsigned long long g_phase[PEDN_PHASE_WAVES * 12];  // [wave of the g
 __device__ __forceinline__ size_t at(int t, int col, int cols, int RS, int r) {
   return ((size_t)t * (size_t)cols + (size_t)col) * (size_t)RS + (size_t)r;
 }
+// start of the 64-replica segment [r0, r0 + 64) of row (t, col): wave-uniform, so `rowp(...)[lane]` is a scalar base plus a
+// 32-bit lane offset (no 64-bit per-lane address arithmetic)
+template <typename T>
+__device__ __forceinline__ T* rowp(T* base, int t, int col, int cols, int RS, int r0) {
+  return base + (((size_t)t * (size_t)cols + (size_t)col) * (size_t)RS + (size_t)r0);
+}
 __device__ __forceinline__ float clip01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 // Link parameters as seen by one lane: the shared record, or (PR) the replica's own k_critical / k_jam / free-flow speed
 // and the quantities derived from them on the host.
@@ -256,7 +262,8 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   // blockIdx.x = replica group (fastest in dispatch order): blocks launched together touch neighbouring 512-byte chunks
   // of the same history rows
-  const int r = (int)blockIdx.x * 64 + lane;
+  const int r0 = (int)blockIdx.x * 64;
+  const int r = r0 + lane;
   const int tp = t - 1;
 #ifdef PEDN_PHASE_PROFILE
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -325,8 +332,8 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     };
     if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
       s_i = v.demand[((size_t)W.demand_row * v.T1 + tp) * RS + r];
-      co_prev = v.f64[F_CO][at(tp, lin, Lall, RS, r)];
-      ci_prev = v.f64[F_CI][at(tp, lout, Lall, RS, r)];
+      co_prev = rowp(v.f64[F_CO], tp, lin, Lall, RS, r0)[lane];
+      ci_prev = rowp(v.f64[F_CI], tp, lout, Lall, RS, r0)[lane];
       if (static_tf) {
         const bool shared = v.tf_u[turn0] == v.tf_u[turn0];  // not NaN
 #pragma unroll
@@ -345,17 +352,17 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       // back to back (a load skipped by a branch costs a wait at the join); the few values of an `early` step are unused
       SlotIn x;
       const int t_sw = tp + 1 - Pout.tau_sw > 0 ? tp + 1 - Pout.tau_sw : 0;
-      x.n_in = v.f32[G_N][at(tp, lin, L, RS, r)];
-      x.n_out = v.f32[G_N][at(tp, lout, L, RS, r)];
+      x.n_in = rowp(v.f32[G_N], tp, lin, L, RS, r0)[lane];
+      x.n_out = rowp(v.f32[G_N], tp, lout, L, RS, r0)[lane];
       // density[t'] of a plain link is num_pedestrians[t'] / float32(length * width) (link.py:136): recomputed from n_in with the
       // link update's own division instead of being read back; a separator's density depends on its width at that time
-      x.k_in = Pin.sep ? v.f32[G_K][at(tp, lin, L, RS, r)] : 0.0f;
-      x.att_in = v.f32[G_ATT][at(tp, lin, L, RS, r)];
-      x.co_in = v.f64[F_CO][at(tp, lin, Lall, RS, r)];
-      x.s_prev = v.f64[F_S][at(tm1, lin, L, RS, r)];
-      x.co_sw = v.f64[F_CO][at(t_sw, lout, Lall, RS, r)];
-      x.ci_out = v.f64[F_CI][at(tp, lout, Lall, RS, r)];
-      x.r_prev = v.f64[F_R][at(tm1, lout, L, RS, r)];
+      x.k_in = Pin.sep ? rowp(v.f32[G_K], tp, lin, L, RS, r0)[lane] : 0.0f;
+      x.att_in = rowp(v.f32[G_ATT], tp, lin, L, RS, r0)[lane];
+      x.co_in = rowp(v.f64[F_CO], tp, lin, Lall, RS, r0)[lane];
+      x.s_prev = rowp(v.f64[F_S], tm1, lin, L, RS, r0)[lane];
+      x.co_sw = rowp(v.f64[F_CO], t_sw, lout, Lall, RS, r0)[lane];
+      x.ci_out = rowp(v.f64[F_CI], tp, lout, Lall, RS, r0)[lane];
+      x.r_prev = rowp(v.f64[F_R], tm1, lout, L, RS, r0)[lane];
       const double fu = v.front_u[lin], bu = v.back_u[lout];
       x.front_in = fu == fu ? fu : v.front[(size_t)lin * RS + r];
       x.back_out = bu == bu ? bu : v.back[(size_t)lout * RS + r];
@@ -373,11 +380,11 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       PH(2, x.n_in + x.k_in + x.att_in + (float)(x.co_in + x.s_prev + x.co_sw + x.ci_out + x.r_prev + x.front_in + x.back_out));
       s_i = early ? 0.0 : send_flow(v, Pin, lin, tp, r, x, fl);
       PH(3, s_i);
-      v.f64[F_S][at(tp, lin, L, RS, r)] = s_i;  // link.py:268,367
+      rowp(v.f64[F_S], tp, lin, L, RS, r0)[lane] = s_i;  // link.py:268,367
       if (s_i < 0.0) fl |= PEDN_F_NEG_FLOW;
       r_i = recv_flow(v, Pout, lout, tp, r, x, s_i, fl);
       PH(4, r_i);
-      v.f64[F_R][at(tp, lout, L, RS, r)] = r_i;  // node.py:206
+      rowp(v.f64[F_R], tp, lout, L, RS, r0)[lane] = r_i;  // node.py:206
     }
     if (s_i < 0.0 || r_i < 0.0) fl |= PEDN_F_NEG_FLOW;
 
@@ -452,10 +459,10 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       if (qo < 0.0 || qi < 0.0) fl |= PEDN_F_NEG_FLOW;
     }
     // Node.update_links (node.py:146-162; link.py:19-25)
-    v.f64[F_OUT][at(t, lin, Lall, RS, r)] = qo;
-    v.f64[F_CO][at(t, lin, Lall, RS, r)] = co_prev + qo;
-    v.f64[F_IN][at(t, lout, Lall, RS, r)] = qi;
-    v.f64[F_CI][at(t, lout, Lall, RS, r)] = ci_prev + qi;
+    rowp(v.f64[F_OUT], t, lin, Lall, RS, r0)[lane] = qo;
+    rowp(v.f64[F_CO], t, lin, Lall, RS, r0)[lane] = co_prev + qo;
+    rowp(v.f64[F_IN], t, lout, Lall, RS, r0)[lane] = qi;
+    rowp(v.f64[F_CI], t, lout, Lall, RS, r0)[lane] = ci_prev + qi;
     if (fl) atomicOr(&v.flags[r], fl);
   }
 #ifdef PEDN_PHASE_PROFILE
