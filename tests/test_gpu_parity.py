@@ -303,8 +303,11 @@ def test_per_replica_widths_and_turning_fractions_via_replica_scope():
     net.close()
 
 
-def test_fuzz_random_networks_engine_equals_oracle():
-    """40 random scenarios (random trees + chords, all three fundamental diagrams, separators, controllers, activity,
+@pytest.mark.parametrize("fuse_tp", ["1", "0"])
+def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, monkeypatch):
+    """(with the next step's turn probabilities fused into the link update launch, and launched on their own: nine of the
+    networks put separator links into softmax groups, whose density the fused launch re-derives)
+    40 random scenarios (random trees + chords, all three fundamental diagrams, separators, controllers, activity,
     noise, odd time steps; the generator of the offline reference campaign oracle/fuzz_vs_reference.py): HIP engine and
     CPU oracle agree bit for bit on every field, every replica, including the sticky error flags."""
     import copy
@@ -312,6 +315,7 @@ def test_fuzz_random_networks_engine_equals_oracle():
     from fuzz_cases import random_case
     from pednstream_amd import Network
 
+    monkeypatch.setenv("PEDN_FUSE_TP", fuse_tp)
     ran = 0
     for seed in range(3000, 3040):
         adj, params, origins, dests = random_case(seed)
