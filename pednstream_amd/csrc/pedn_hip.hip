@@ -31,6 +31,7 @@ struct pedn_sim {
   int device = 0;
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
   int node_waves = 6;  // register budget of node_kernel, see its comment
+  int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
   int fuse_tp = 0;     // the link update and the next step's turn probabilities share one launch (launch_step)
   int tp_ran = 0;      // launch_step launched the stand-alone turn_prob_kernel (pedn_profile_step)
   int tp_ready = -1;   // step whose turn probabilities are in ent_p (written by link_turn_kernel of the step before), -1: none
@@ -405,6 +406,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // 16 bytes per entry): with many groups the separate launch is as fast (delft x 1024: 59.9 fused, 58.4 separate).
     s->fuse_tp = (size_t)v.n_multi * v.RS <= (size_t)131072;
     if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
+    if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
     TRY(upload(s, rec.data(), rec.size(), &v.slot_rec));
   }
   // ---- dynamic state
@@ -697,12 +699,15 @@ static node_kernel_fn node_kernel_for(const pedn_sim* s) {
   return s->node_waves == 8 ? node_kernel<false, 8> : node_kernel<false, 6>;
 }
 
-// One step = node_kernel(t), then the link update of t -- fused, for models with softmax groups, with the turn probabilities
-// of t+1.  ev != nullptr: per-launch start/stop events {turn_prob, node, link} for pedn_profile_step.
-static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr) {
+// One step = node_kernel(t), then ONE launch with the link update of t and -- where they apply -- the turn probabilities of
+// t+1 (models with softmax groups) and the RL observations / rewards of t (observe >= 0: the accumulate flag of
+// rl_observe; only pedn_rl_step asks for it).  ev != nullptr: per-launch start/stop events {turn_prob, node, link} for
+// pedn_profile_step.  Returns 1 through *observed when the observations were part of the launch.
+static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe = -1, bool* observed = nullptr) {
   DevView& v = s->v;
   const unsigned rgroups = (unsigned)(v.RS / 64);
   const bool groups = v.n_multi > 0, fused = groups && s->fuse_tp;
+  const bool obs_fused = observe >= 0 && s->rl_ready && s->fuse_obs;
   auto launch = [&](auto kernel, dim3 grid, dim3 block, int e, auto... args) {
     if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, s->stream, ev[e], ev[e + 1], 0, args...);
     else hipLaunchKernelGGL(kernel, grid, block, 0, s->stream, args...);
@@ -714,16 +719,26 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr) {
     s->tp_ran = 1;
   }
   launch(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 2, v, t);
-  const unsigned nlb = (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2) + 255) / 256);
-  if (fused) {
-    const unsigned ntb = (unsigned)(((size_t)v.n_multi * v.RS + 255) / 256);
-    if (v.pr) launch(link_turn_kernel<true>, dim3(nlb + ntb), dim3(256), 4, v, t, nlb);
-    else launch(link_turn_kernel<false>, dim3(nlb + ntb), dim3(256), 4, v, t, nlb);
-    s->tp_ready = t + 1;
+  const unsigned nlb = v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2) + 255) / 256) : 0u;
+  if (fused || obs_fused) {
+    const unsigned ntb = fused ? (unsigned)(((size_t)v.n_multi * v.RS + 255) / 256) : 0u;
+    const unsigned nob = obs_fused ? (unsigned)s->rl.n_agents * rgroups : 0u;  // one block per (agent, 64 replicas)
+    RlView q = s->rl;
+    if (!obs_fused) q.n_agents = 0;
+    const int acc = observe > 0 ? 1 : 0;
+    if (obs_fused) {
+      if (v.pr) launch(link_turn_kernel<true, true>, dim3(nlb + ntb + nob), dim3(256), 4, v, t, nlb, ntb, q, acc);
+      else launch(link_turn_kernel<false, true>, dim3(nlb + ntb + nob), dim3(256), 4, v, t, nlb, ntb, q, acc);
+    } else {
+      if (v.pr) launch(link_turn_kernel<true, false>, dim3(nlb + ntb), dim3(256), 4, v, t, nlb, ntb, q, acc);
+      else launch(link_turn_kernel<false, false>, dim3(nlb + ntb), dim3(256), 4, v, t, nlb, ntb, q, acc);
+    }
+    if (fused) s->tp_ready = t + 1;
   } else if (v.n_pairs_corr > 0) {
     if (v.pr) launch(link_kernel_pr, dim3(nlb), dim3(256), 4, v, t);
     else launch(link_kernel, dim3(nlb), dim3(256), 4, v, t);
   }
+  if (observed) *observed = obs_fused;
   return PEDN_OK;
 }
 
@@ -1011,7 +1026,7 @@ int pedn_rl_observe(pedn_sim* s, int32_t t, int32_t accumulate, float* obs, floa
   HIP_TRY(s, hipSetDevice(s->device));
   DevView& v = s->v;
   RlView& q = s->rl;
-  hipLaunchKernelGGL(rl_observe_kernel, dim3((unsigned)(v.RS / 64), (unsigned)q.n_agents), dim3(512), 0, s->stream, v, q, t, accumulate);
+  hipLaunchKernelGGL(rl_observe_kernel, dim3((unsigned)q.n_agents * (unsigned)(v.RS / 64)), dim3(256), 0, s->stream, v, q, t, accumulate);
   HIP_TRY(s, hipGetLastError());
   if (obs) HIP_TRY(s, hipMemcpyAsync(obs, q.obs, (size_t)v.R * q.O * sizeof(float), hipMemcpyDeviceToHost, s->stream));
   if (rewards) HIP_TRY(s, hipMemcpyAsync(rewards, q.rew, (size_t)v.R * q.n_agents * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -1024,10 +1039,19 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
   if (action_gap < 1 || t < 1 || t + action_gap - 1 > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
   int rc = PEDN_OK;
   if (actions && (rc = pedn_rl_apply_actions(s, actions, on_device)) != PEDN_OK) return rc;
+  RlView& q = s->rl;
   for (int k = 0; k < action_gap; ++k) {
-    launch_step(s, t + k);
     const bool last = k == action_gap - 1;
-    if ((rc = pedn_rl_observe(s, t + k, k > 0, last ? obs : nullptr, last ? rewards : nullptr)) != PEDN_OK) return rc;
+    bool observed = false;
+    launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed);
+    HIP_TRY(s, hipGetLastError());
+    if (!observed) {
+      if ((rc = pedn_rl_observe(s, t + k, k > 0, last ? obs : nullptr, last ? rewards : nullptr)) != PEDN_OK) return rc;
+    } else if (last && (obs || rewards)) {
+      if (obs) HIP_TRY(s, hipMemcpyAsync(obs, q.obs, (size_t)s->v.R * q.O * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+      if (rewards) HIP_TRY(s, hipMemcpyAsync(rewards, q.rew, (size_t)s->v.R * q.n_agents * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(s, hipStreamSynchronize(s->stream));
+    }
   }
   return PEDN_OK;
 }

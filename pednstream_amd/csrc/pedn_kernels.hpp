@@ -628,20 +628,6 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
 __global__ __launch_bounds__(256) void link_kernel(DevView v, int t) { link_body(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
 __global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) { link_pr_body(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
 
-// Models with softmax groups: ONE launch after node_kernel(t) holds the link update of step t (blocks < n_link_blocks) and the
-// turn probabilities of step t+1 (the other blocks).  Both read only what node_kernel(t) and earlier launches wrote, so they
-// are independent; a separate turn-probability launch cost 6-9 us per step, most of it the fixed cost of a launch.
-template <bool PR>
-__global__ __launch_bounds__(256) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks) {
-  if (blockIdx.x < n_link_blocks) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (PR) link_pr_body(v, t, gid);
-    else link_body(v, t, gid);
-  } else {
-    turn_prob_body<PR, true>(v, t + 1, (size_t)(blockIdx.x - n_link_blocks) * blockDim.x + threadIdx.x);
-  }
-}
-
 // ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------
 struct RlView {
   const int32_t *agent_type, *agent_link_ptr, *agent_links, *agent_act_off, *agent_obs_off;
@@ -681,21 +667,28 @@ __global__ void rl_apply_kernel(DevView v, RlView q) {
   }
 }
 
-// ObservationBuilder + _compute_rewards.  Block = (agent, 64 replicas); wave w = the agent's w-th controlled link: its
-// features go straight to the observation row, its reward terms to LDS; wave 0 then folds them in the reference's order.
-__global__ __launch_bounds__(512) void rl_observe_kernel(DevView v, RlView q, int t, int accumulate) {
+// ObservationBuilder.build_observation (builders.py:68-238) and PedNetParallelEnv._compute_rewards (pz_pednet_env.py:548-581)
+// for every env.  Block of 4 waves = (agent, 64 replicas); wave w takes the agent's links w and w + 4: their observation
+// features, and travel-time / density terms into LDS; wave 0 then folds the reward in link order (float32, like the
+// reference).  FUSED: the block runs inside link_turn_kernel next to the link update of the same step, which has not stored
+// travel time, speed and density of step t yet: they are recomputed for the agent's links with the link update's own
+// arithmetic (speed_calc with the same Philox key), so the parts of that launch stay independent.
+template <bool FUSED>
+__device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& q, int t, int accumulate, unsigned block) {
   __shared__ float sT[PEDN_MAX_DEGREE][64], sD[PEDN_MAX_DEGREE][64], sKc[PEDN_MAX_DEGREE][64];
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int lane = (int)(threadIdx.x & 63);
-  const int r = (int)blockIdx.x * 64 + lane;
-  const int ag = (int)blockIdx.y;
   const int RS = v.RS, L = v.L, Lall = v.Lall;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned rgroups = (unsigned)(RS / 64);
+  const int ag = (int)(block / rgroups);
+  const int r = (int)(block % rgroups) * 64 + lane;
+  if (ag >= q.n_agents) return;  // block-uniform
   const int la = q.agent_link_ptr[ag], n = q.agent_link_ptr[ag + 1] - la;
   const int type = q.agent_type[ag];
   const bool live = r < v.R;
   float* o = q.obs + (size_t)(live ? r : 0) * q.O + q.agent_obs_off[ag];
   if (type == 0) {  // separator agent, builders.py:87-117
-    if (w == 0 && live) {
+    if (wv == 0 && live) {
       const int f = q.agent_links[la], b = q.agent_links[la + 1];
       float x[4] = {(float)v.f64[F_IN][at(t, f, Lall, RS, r)], (float)v.f64[F_OUT][at(t, f, Lall, RS, r)],
                     (float)v.f64[F_IN][at(t, b, Lall, RS, r)], (float)v.f64[F_OUT][at(t, b, Lall, RS, r)]};
@@ -704,35 +697,55 @@ __global__ __launch_bounds__(512) void rl_observe_kernel(DevView v, RlView q, in
         o[k] = x[k];
       }
     }
-  } else if (w < n) {  // gater agent, link w: builders.py:119-177
-    const int l = q.agent_links[la + w];
-    const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
-    const float in_l = (float)v.f64[F_IN][at(t, l, Lall, RS, r)], out_l = (float)v.f64[F_OUT][at(t, l, Lall, RS, r)];
-    const float in_r = (float)v.f64[F_IN][at(t, P.rev, Lall, RS, r)], out_r = (float)v.f64[F_OUT][at(t, P.rev, Lall, RS, r)];
-    const float tt_l = v.f32[G_TT][at(t, l, L, RS, r)], tt_r = v.f32[G_TT][at(t, P.rev, L, RS, r)];
-    const float spd = q.obs_mode == 5 ? v.f32[G_V][at(t, l, L, RS, r)] : 0.0f;
-    const float dens = dens_at(v, P, l, t, r);
-    const float gate = (float)v.back[(size_t)l * RS + r];
-    if (live) {
-      float* oi = o + w * q.fpl;
-      switch (q.obs_mode) {
-        case 1: oi[0] = in_l; oi[1] = out_r; oi[2] = gate; break;
-        case 2: oi[0] = in_l; oi[1] = out_r; oi[2] = dens; oi[3] = gate; break;
-        case 3: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = gate; break;
-        case 4: oi[0] = dens / (float)P.kj; oi[1] = gate; break;
-        default: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = spd; oi[5] = dens; oi[6] = gate;
+  } else {  // gater agent, builders.py:119-177
+#pragma unroll 1
+    for (int w = wv; w < n; w += 4) {
+      const int l = q.agent_links[la + w];
+      const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
+      const double in_ld = v.f64[F_IN][at(t, l, Lall, RS, r)], out_ld = v.f64[F_OUT][at(t, l, Lall, RS, r)];
+      const double in_rd = v.f64[F_IN][at(t, P.rev, Lall, RS, r)], out_rd = v.f64[F_OUT][at(t, P.rev, Lall, RS, r)];
+      const float in_l = (float)in_ld, out_l = (float)out_ld, in_r = (float)in_rd, out_r = (float)out_rd;
+      float tt_l, tt_r, spd, dens;
+      if (!FUSED) {
+        tt_l = v.f32[G_TT][at(t, l, L, RS, r)];
+        tt_r = v.f32[G_TT][at(t, P.rev, L, RS, r)];
+        spd = q.obs_mode == 5 ? v.f32[G_V][at(t, l, L, RS, r)] : 0.0f;
+        dens = dens_at(v, P, l, t, r);
+      } else {  // link.py:133-136 + update_speeds, as in link_body
+        const LinkP Pr = v.pr ? lane_params<true>(v, v.lp[P.rev], P.rev, r) : v.lp[P.rev];
+        const float na = (float)((double)v.f32[G_N][at(t - 1, l, L, RS, r)] + (in_ld - out_ld));
+        const float nb = (float)((double)v.f32[G_N][at(t - 1, P.rev, L, RS, r)] + (in_rd - out_rd));
+        const double wa = P.sep ? v.sepw[(size_t)l * RS + r] : P.width, wb = Pr.sep ? v.sepw[(size_t)P.rev * RS + r] : Pr.width;
+        const float ka = (P.sep && v.sepnp[(size_t)l * RS + r] != 0.0) ? (float)((double)na / (P.length * wa)) : na / (float)(P.length * wa);
+        const float kb = (Pr.sep && v.sepnp[(size_t)P.rev * RS + r] != 0.0) ? (float)((double)nb / (Pr.length * wb)) : nb / (float)(Pr.length * wb);
+        const SpeedOut sa = speed_calc(v, P, l, t, r, ka, kb, 0.0f, 0.0f), sb = speed_calc(v, Pr, P.rev, t, r, kb, ka, 0.0f, 0.0f);
+        tt_l = sa.tt;
+        tt_r = sb.tt;
+        spd = sa.spd;
+        dens = P.sep ? ka : (na + nb) / (float)(P.length * P.width);  // Link.get_density / Separator.get_density at t
       }
-      if (q.normalize) {  // builders.py:204-238, applied literally
-        if (q.obs_mode == 1 || q.obs_mode == 2) { oi[0] = oi[0] / 20.0f; oi[1] = oi[1] / 20.0f; }
-        else if (q.obs_mode == 3) { oi[0] = oi[0] / 6.0f; oi[1] = oi[1] / 20.0f; oi[2] = oi[2] / 20.0f; }
+      const float gate = (float)v.back[(size_t)l * RS + r];
+      if (live) {
+        float* oi = o + w * q.fpl;
+        switch (q.obs_mode) {
+          case 1: oi[0] = in_l; oi[1] = out_r; oi[2] = gate; break;
+          case 2: oi[0] = in_l; oi[1] = out_r; oi[2] = dens; oi[3] = gate; break;
+          case 3: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = gate; break;
+          case 4: oi[0] = dens / (float)P.kj; oi[1] = gate; break;
+          default: oi[0] = in_l; oi[1] = out_l; oi[2] = in_r; oi[3] = out_r; oi[4] = spd; oi[5] = dens; oi[6] = gate;
+        }
+        if (q.normalize) {  // builders.py:204-238, applied literally
+          if (q.obs_mode == 1 || q.obs_mode == 2) { oi[0] = oi[0] / 20.0f; oi[1] = oi[1] / 20.0f; }
+          else if (q.obs_mode == 3) { oi[0] = oi[0] / 6.0f; oi[1] = oi[1] / 20.0f; oi[2] = oi[2] / 20.0f; }
+        }
       }
+      sT[w][lane] = tt_l + tt_r;  // T_ell + T_ell_reverse, float32 (pz_pednet_env.py:566)
+      sD[w][lane] = dens;
+      sKc[w][lane] = (float)P.kc;
     }
-    sT[w][lane] = tt_l + tt_r;  // T_ell + T_ell_reverse, float32 (pz_pednet_env.py:566)
-    sD[w][lane] = dens;
-    sKc[w][lane] = (float)P.kc;
   }
   __syncthreads();
-  if (w == 0 && live) {
+  if (wv == 0 && live) {
     float reward = 0.0f;
     bool rewarded = false;
     if (type == 1) {  // reward terms in link order, float32 throughout (pz_pednet_env.py:557-577)
@@ -756,6 +769,30 @@ __global__ __launch_bounds__(512) void rl_observe_kernel(DevView v, RlView q, in
     float* rw = q.rew + (size_t)r * q.n_agents + ag;
     const float add = rewarded ? reward : 0.0f;
     *rw = (accumulate && rewarded) ? *rw + add : (accumulate ? *rw : add);
+  }
+}
+
+__global__ __launch_bounds__(256) void rl_observe_kernel(DevView v, RlView q, int t, int accumulate) {
+  rl_observe_body<false>(v, q, t, accumulate, blockIdx.x);
+}
+
+// ONE launch after node_kernel(t) for everything that only reads what node_kernel(t) and earlier launches wrote:
+//   blocks [0, n_link)              the link update of step t
+//   blocks [n_link, n_link + n_tp)  the turn probabilities of step t+1 (models with softmax groups)
+//   the remaining blocks            observations and rewards of step t for the batched RL env (q.n_agents > 0)
+// The parts are independent (the second and third re-derive what the first is about to store), so they run side by side;
+// as separate launches each of them cost 5-9 us, most of it the fixed cost of a launch.
+// (OBS = false: the instantiation ordinary stepping uses carries neither the LDS nor the registers of the third part)
+template <bool PR, bool OBS>
+__global__ __launch_bounds__(256) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, RlView q, int accumulate) {
+  if (blockIdx.x < n_link_blocks) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (PR) link_pr_body(v, t, gid);
+    else link_body(v, t, gid);
+  } else if (blockIdx.x < n_link_blocks + n_tp_blocks) {
+    turn_prob_body<PR, true>(v, t + 1, (size_t)(blockIdx.x - n_link_blocks) * blockDim.x + threadIdx.x);
+  } else if (OBS) {
+    rl_observe_body<true>(v, q, t, accumulate, blockIdx.x - n_link_blocks - n_tp_blocks);
   }
 }
 
