@@ -253,6 +253,18 @@ def test_c_abi_argument_errors_and_reset():
     assert lib.pedn_set_demand(e._h, net.nodes[0].index, -1, np.zeros(4).ctypes.data_as(C.POINTER(C.c_double)), 4) < 0  # node 0 has no virtual link
     with pytest.raises(IndexError):
         net.network_loading(10 ** 6)
+    # demand entry points: bad node / replica / length / pattern are refused with a message, nothing is launched
+    origin = next(n for n in net.nodes.values() if n.virtual_incoming_link is not None and n.node_id in net.origin_nodes)
+    F, I = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    buf = np.zeros(3 * (e.T + 2))
+    assert lib.pedn_set_demand_matrix(e._h, net.nodes[0].index, buf.ctypes.data_as(F), 4) < 0
+    assert lib.pedn_set_demand_matrix(e._h, origin.index, buf.ctypes.data_as(F), e.T + 2) < 0 and b"time indices" in lib.pedn_last_error(e._h)
+    assert lib.pedn_get_demand(e._h, origin.index, 3, buf.ctypes.data_as(F), 4) < 0 and b"replica" in lib.pedn_last_error(e._h)
+    pat, zi, zf = np.array([0, 7, 0], np.int32), np.zeros(3, np.int32), np.zeros(3)
+    assert lib.pedn_draw_demand(e._h, origin.index, 1, pat.ctypes.data_as(I), zf.ctypes.data_as(F), zf.ctypes.data_as(F), zi.ctypes.data_as(I),
+                                zi.ctypes.data_as(I), zf.ctypes.data_as(F)) < 0 and b"pattern" in lib.pedn_last_error(e._h)
+    before = e.get_demand(origin.index, 1)
+    assert np.array_equal(before[:len(origin.demand)], np.asarray(origin.demand, dtype=float))     # nothing was overwritten
     net.run(1, 50)
     a = e.read_block(2, 0, 50)
     e.reset()
