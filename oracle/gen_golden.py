@@ -391,6 +391,15 @@ CASES.update({
     "rl_i45_opt3": lambda: rl_case("rl_i45_opt3", "45_intersections", obs_mode="option3", env_steps=200, action_seed=5),
     "rl_corridor_opt1": lambda: rl_case("rl_corridor_opt1", "long_corridor", obs_mode="option1", env_steps=200, action_seed=6),
 })
+CASES.update({   # the remaining scenario directories of the reference's data/ (RL datasets with controller nodes)
+    "butterfly_scA_full": lambda: scenario_case("butterfly_scA_full", "butterfly_scA", seed=3, replica=1),
+    "butterfly_scB_full": lambda: scenario_case("butterfly_scB_full", "butterfly_scB", seed=3, replica=2),
+    "butterfly_scC_full": lambda: scenario_case("butterfly_scC_full", "butterfly_scC", seed=3, replica=3),
+    "one_intersection_full": lambda: scenario_case("one_intersection_full", "one_intersection_v0", seed=4, replica=0),
+    "two_coordinators_prefix": lambda: scenario_case("two_coordinators_prefix", "two_coordinators", steps=260, seed=5, replica=4),
+    "rl_butterfly_opt3": lambda: rl_case("rl_butterfly_opt3", "butterfly_scC", obs_mode="option3", env_steps=200, action_seed=7),
+    "rl_one_intersection_opt5": lambda: rl_case("rl_one_intersection_opt5", "one_intersection_v0", obs_mode="option5", env_steps=200, action_seed=8),
+})
 for _r in range(4):
     CASES[f"nine_replica{_r}"] = (lambda r=_r: scenario_case(
         f"nine_replica{r}", "nine_intersections", steps=160, seed=0, replica=r,
