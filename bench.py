@@ -175,9 +175,8 @@ def main():
     T = net.simulation_steps
     e = net.engine()
     origins = list(net.origin_nodes)
-    for r in range(R):
-        for nid in origins:
-            e.set_demand(net.nodes[nid].index, replica_demand(T, offset + r), replica=r)
+    for k, nid in enumerate(origins):          # one upload per origin: [R, T] rows keyed by the global replica id
+        e.set_demand_matrix(net.nodes[nid].index, np.stack([replica_demand(T, offset + r) for r in range(R)]))
     net._dirty_demand = set()
     e.synchronize()
     L = e.n_links

@@ -31,9 +31,8 @@ def main():
         R = 1024
         net = gen.create_network(network, verbose=False, n_replicas=R, rng_seed=0)
         e = net.engine()
-        for r in range(R):
-            for nid in net.origin_nodes:
-                e.set_demand(net.nodes[nid].index, replica_demand(net.simulation_steps, r), replica=r)
+        for nid in net.origin_nodes:
+            e.set_demand_matrix(net.nodes[nid].index, np.stack([replica_demand(net.simulation_steps, r) for r in range(R)]))
         net._dirty_demand = set()
         e.run(1, 150)
         e.synchronize()

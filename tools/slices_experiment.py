@@ -25,9 +25,8 @@ def build(network, n, offset):
     gen = NetworkEnvGenerator(os.path.join(ROOT, "data"))
     net = gen.create_network(network, verbose=False, n_replicas=n, replica_offset=offset, rng_seed=0, device=0)
     e = net.engine()
-    for r in range(n):
-        for nid in net.origin_nodes:
-            e.set_demand(net.nodes[nid].index, replica_demand(net.simulation_steps, offset + r), replica=r)
+    for nid in net.origin_nodes:
+        e.set_demand_matrix(net.nodes[nid].index, np.stack([replica_demand(net.simulation_steps, offset + r) for r in range(n)]))
     net._dirty_demand = set()
     e.synchronize()
     return net, e
