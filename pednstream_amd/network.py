@@ -248,6 +248,17 @@ class LinkView(BaseLinkView):
             n = n + self.reverse_link.num_pedestrians[time_step]
         return n / np.float32(self.area)
 
+    def get_outflow(self, time_step: int, tau: int):
+        """Diffusion outflow of link.py:199-214 from the device histories (the device evaluates it inside the sending flow;
+        this is the read-only view for callers that inspect it): the last four inflows from ``tau`` steps ago weighted
+        F, F(1-F), F(1-F)^2, F(1-F)^3 with F = 1 / (1 + gamma * avg_travel_time), rounded up, never negative."""
+        F = 1 / (1 + self.gamma * self.avg_travel_time[time_step])
+        G = 1 - F
+        flow = F * self.inflow[time_step - tau]
+        for k, weight in ((1, F * G), (2, F * G ** 2), (3, F * G ** 3)):
+            flow = flow + weight * self.inflow[time_step - tau - k]
+        return max(np.ceil(flow), 0)
+
 
 class NodeView:
     """Node of the network (node.py:6-26).  ``kind`` is 'one_to_one' or 'regular' (network.py:141-167)."""

@@ -279,6 +279,31 @@ def test_c_abi_argument_errors_and_reset():
     net.close()
 
 
+def test_link_view_methods_on_device_histories():
+    """LinkView.get_density / get_outflow (link.py:190-214) evaluated on the host from fetched histories agree with the
+    oracle's arithmetic (float32 scalar powers = glibc powf)."""
+    g = Golden("nine_full")
+    net = build_network(g)
+    net.run(1, 120)
+    L = od.lib()
+    checked = 0
+    for link in list(net.links.values())[:8]:
+        inflow, att = np.asarray(link.inflow), np.asarray(link.avg_travel_time)
+        N, Nr = np.asarray(link.num_pedestrians), np.asarray(link.reverse_link.num_pedestrians)
+        for t in (40, 80, 119):
+            tau = int(round(float(att[t]) / net.unit_time))
+            F = np.float32(1.0) / (np.float32(1.0) + np.float32(link.gamma) * att[t])
+            G = np.float32(1.0) - F
+            G2, G3 = np.float32(L.pedn_oracle_powf(float(G), 2.0)), np.float32(L.pedn_oracle_powf(float(G), 3.0))
+            want = (np.float64(F) * inflow[t - tau] + np.float64(F * G) * inflow[t - tau - 1] + np.float64(F * G2) * inflow[t - tau - 2]
+                    + np.float64(F * G3) * inflow[t - tau - 3])
+            assert link.get_outflow(t, tau) == max(np.ceil(want), 0)
+            assert link.get_density(t) == (N[t] + Nr[t]) / np.float32(link.length * link.width)
+            checked += 1
+    assert checked == 24
+    net.close()
+
+
 def test_per_replica_widths_and_turning_fractions_via_replica_scope():
     """`with network.replica(r)` scopes setters to one replica (the replica-uniform fast path must fall back to the
     per-replica rows); every replica is checked against a CPU oracle run with that replica's settings."""
