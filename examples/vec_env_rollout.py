@@ -8,6 +8,11 @@ import time
 
 import numpy as np
 
+try:
+    import torch  # noqa: F401  -- before the engine library is loaded: one HIP runtime per process (see VecPedNetEnv.step_device)
+except ImportError:
+    torch = None
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pednstream_amd.rl_env import VecPedNetEnv  # noqa: E402
 
@@ -28,6 +33,27 @@ def main():
     dt = time.perf_counter() - t0
     print(f"{n_envs * steps / dt:.3g} env-steps/s including host-side action sampling and obs/reward copies; "
           f"mean return of the first agent {ret.mean():.1f}")
+
+    # the same rollout with the policy on the GPU: actions are sampled by torch on the device, observations and rewards are
+    # torch views of the engine's buffers -- nothing crosses PCIe
+    if torch is None:
+        env.close()
+        return
+    env.reset(options={"randomize": True, "mode": "vectorised"}, seed=2)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    low = torch.as_tensor(env.action_low, device="cuda", dtype=torch.float64)
+    span = torch.as_tensor(env.action_high, device="cuda", dtype=torch.float64) - low
+    ret_d = torch.zeros(n_envs, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        actions = low + span * torch.rand((n_envs, env.n_actions), generator=gen, device="cuda", dtype=torch.float64)
+        obs, rew, terminated = env.step_device(actions)
+        ret_d += rew[:, 0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{n_envs * steps / dt:.3g} env-steps/s with the random policy on the GPU (step_device); "
+          f"mean return of the first agent {float(ret_d.mean()):.1f}")
     env.close()
 
 

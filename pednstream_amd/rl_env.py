@@ -123,6 +123,14 @@ class AgentManager:
         return ids, np.array(types, np.int32), np.array(ptr, np.int32), np.array(links, np.int32)
 
 
+class _DeviceBuffer:
+    """A raw device pointer dressed up for ``torch.as_tensor`` (``__cuda_array_interface__``, version 2)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape), "typestr": typestr, "version": 2,
+                                         "strides": None}
+
+
 class VecPedNetEnv:
     """``n_envs`` replicas of one scenario stepped together on one GPU."""
 
@@ -172,6 +180,7 @@ class VecPedNetEnv:
             o0 += no
         self.action_low, self.action_high = np.array(lo, np.float32), np.array(hi, np.float32)
         self.sim_step = 1
+        self._device_views = None
 
     # ------------------------------------------------------------------------------------------------ API
     def randomize(self, seed=None, mode="reference"):
@@ -232,6 +241,43 @@ class VecPedNetEnv:
         self.network._widths_stale = True
         terminated = (self.sim_step - 1) >= self.simulation_steps     # pz_pednet_env.py:592 evaluated before the increment
         return obs, rew, terminated, False, {}
+
+    def step_device(self, actions):
+        """``step`` for an on-GPU learner: ``actions`` is a torch CUDA tensor (float64, [n_envs, n_actions], contiguous) or None;
+        returns ``(obs, rewards, terminated)`` where obs [n_envs, n_obs] and rewards [n_envs, n_agents] are float32 torch tensors
+        that ALIAS the engine's device buffers (``pedn_rl_device_ptr``) -- no host copy.  They are overwritten by the next
+        step, so clone what must be kept.  The call waits for the caller's current torch stream before launching and for the
+        engine's stream before returning, so plain sequential use is safe.
+
+        torch ships its own copy of the HIP runtime: ``import torch`` BEFORE the first engine of the process is created (the
+        engine library then binds to the copy torch loaded; the other way round the process ends up with two runtimes and torch
+        reports "No HIP GPUs are available")."""
+        import torch
+
+        if self.sim_step + self.action_gap - 1 > self.simulation_steps:
+            raise IndexError("episode is over; call reset()")
+        eng = self.network._flush()
+        ptr = 0
+        if actions is not None:
+            if not (actions.is_cuda and actions.dtype == torch.float64 and actions.is_contiguous()
+                    and tuple(actions.shape) == (self.n_envs, self.n_actions)):
+                raise ValueError(f"actions must be a contiguous float64 CUDA tensor of shape {(self.n_envs, self.n_actions)}")
+            torch.cuda.current_stream(actions.device).synchronize()
+            ptr = actions.data_ptr()
+        if ptr:
+            eng.rl_step_device(ptr, self.sim_step, self.action_gap)
+        else:
+            eng.rl_step(None, self.sim_step, self.action_gap, fetch=False)
+        eng.synchronize()
+        self.sim_step += self.action_gap
+        self.network.current_step = self.sim_step - 1
+        self.network._widths_stale = True
+        if self._device_views is None:
+            dev = torch.device("cuda", self.network.device)
+            view = lambda which, cols: torch.as_tensor(_DeviceBuffer(eng.rl_device_ptr(which), (self.n_envs, cols), "<f4"), device=dev)
+            self._device_views = (view(1, self.n_obs), view(2, len(self.possible_agents)))
+        obs, rew = self._device_views
+        return obs, rew, (self.sim_step - 1) >= self.simulation_steps
 
     def split_obs(self, obs_row):
         return {aid: obs_row[..., sl] for aid, sl in self.obs_slices.items()}
