@@ -30,11 +30,11 @@ struct pedn_sim {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int device = 0;
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
-  int node_waves = 6;  // register budget of node_kernel, see its comment
+  int node_waves = 8;  // register budget of node_kernel, see pedn_create
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
   int fuse_tp = 0;     // the link update and the next step's turn probabilities share one launch (launch_step)
-  int tp_ran = 0;      // launch_step launched the stand-alone turn_prob_kernel (pedn_profile_step)
-  int tp_ready = -1;   // step whose turn probabilities are in ent_p (written by link_turn_kernel of the step before), -1: none
+  int tp_ran = 0;      // launch_step launched the stand-alone turn_frac_kernel (pedn_profile_step)
+  int tp_ready = -1;   // step whose turning fractions are in tfd[step & 1] (written by link_turn_kernel of the step before), -1: none
   std::vector<int32_t> node_turn_ptr, node_demand_row;
   std::vector<int32_t> h_up_od_ptr, h_upod_od, h_pair_upod;  // route-choice tables needed to re-tabulate P(od | up)
   std::vector<double> h_od_w;
@@ -45,12 +45,18 @@ struct pedn_sim {
   bool rl_ready = false;
   std::vector<double> h_front_u, h_back_u, h_tf_u;
   double *d_front_u = nullptr, *d_back_u = nullptr, *d_tf_u = nullptr;
-  std::vector<int32_t> h_node_dyn;
+  std::vector<int32_t> h_node_dyn, h_slot_dyn;  // per node: dynamic; per slot: SlotRec.dyn (0 static, 1 turn_frac_kernel, 2 tabulated)
+  std::vector<int32_t> h_node_slot_ptr;
+  std::vector<double> h_ttab, h_ttab_r;         // host copies of turn_tab [T+1][n_turns] / turn_tab_r [n_turns][R] (tabulated rows: final values)
   std::vector<char> h_rl_link;
   double *d_kc_r = nullptr, *d_kj_r = nullptr, *d_vf_r = nullptr, *d_pair_pod_r = nullptr, *d_turn_tab_r = nullptr;
   int32_t *d_fft_r = nullptr, *d_tausw_r = nullptr;
   float* d_tt0_r = nullptr;  // links whose widths the RL action kernel writes per replica: never uniform
-  int n_pair = 0, n_up = 0;
+  int n_pair = 0, n_up = 0, n_over = 0;
+  long step_epoch = 1;  // counts launched steps; h_tf_set_epoch[node] == step_epoch: fractions imposed since the last step
+  std::vector<long> h_tf_set_epoch;
+  std::vector<int32_t> dbg_rwords, dbg_gwords, dbg_prow;
+  int last_t = -1;     // last step launched (pedn_get_turning_fractions: which buffer holds a dynamic node's fractions)
   std::vector<void*> allocs;
   void* stage = nullptr;
   size_t stage_bytes = 0;
@@ -128,6 +134,25 @@ static int push_uniform(pedn_sim* s) {
   return PEDN_OK;
 }
 
+// check_fractions (path_finder.py:691-715) for the rows whose fractions are tabulated on the host (SlotRec.dyn == 2): the
+// same binary64 operations the device applies to the other rows.  tab[turn * stride] holds the raw sums.
+static void finish_tabulated_rows(const pedn_sim* s, double* tab, size_t stride) {
+  for (int n = 0; n < s->n_nodes; ++n) {
+    const int s0 = s->h_node_slot_ptr[n], d = s->h_node_slot_ptr[n + 1] - s0;
+    for (int i = 0; i < d; ++i) {
+      if (s->h_slot_dyn[s0 + i] != 2) continue;
+      const int ta = s->node_turn_ptr[n] + i * (d - 1);
+      double rowsum = 0.0;
+      for (int jj = 0; jj < d - 1; ++jj) rowsum = (jj == 0) ? tab[(size_t)(ta + jj) * stride] : rowsum + tab[(size_t)(ta + jj) * stride];
+      if (fabs(rowsum - 1) > 1e-3)
+        for (int jj = 0; jj < d - 1; ++jj) {
+          double& f = tab[(size_t)(ta + jj) * stride];
+          f = rowsum > 1e-6 ? f / rowsum : 1.0 / (double)(d - 1);
+        }
+    }
+  }
+}
+
 // P(od | up)[t] = w_od[t] / sum over the upstream's ODs (uniform when the sum is 0), path_finder.py:599-615; the sum runs in
 // table order.  Replica independent, so it is tabulated once per (step, product) on the host with the same binary64 operations.
 static int tabulate_pair_pod(pedn_sim* s) {
@@ -155,6 +180,8 @@ static int tabulate_pair_pod(pedn_sim* s) {
       for (int q = s->h_turn_pair_ptr[tn]; q < s->h_turn_pair_ptr[tn + 1]; ++q) acc += 1.0 * table[(size_t)t * np + q];
       ttab[(size_t)t * nt + tn] = acc;
     }
+  for (int t = 0; t < T1; ++t) finish_tabulated_rows(s, &ttab[(size_t)t * nt], 1);
+  s->h_ttab = ttab;
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemcpy(s->d_pair_pod, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(s, hipMemcpy(s->d_turn_tab, ttab.data(), ttab.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -224,8 +251,11 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   v.replica_offset = (uint32_t)replica_offset;
   v.meanfield = rng_mode == PEDN_RNG_MEANFIELD;
   v.n_grp = m->n_grp;
+  if (const char* d = getenv("PEDN_DBG")) v.dbg = atoi(d);
   s->n_nodes = N; s->n_turns = m->n_turns; s->n_demand = m->n_demand; s->n_od = m->n_od; s->n_ent = m->n_ent;
   s->node_turn_ptr.assign(m->node_turn_ptr, m->node_turn_ptr + N + 1);
+  s->h_node_slot_ptr.assign(m->node_slot_ptr, m->node_slot_ptr + N + 1);
+  s->h_tf_set_epoch.assign(N, 0);
   s->node_demand_row.assign(m->node_demand_row, m->node_demand_row + N);
 
 #define TRY(expr) do { int _rc = (expr); if (_rc != PEDN_OK) { std::string keep = g_last_error; pedn_destroy(s); g_last_error = keep; return _rc; } } while (0)
@@ -282,42 +312,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // exp(x)/exp(x) == 1 exactly as long as exp(x) is finite and non-zero; |x| <= temp * (|alpha| + |beta|*k_max/8 + |omega| + |eps|)
     const double xmax = fabs(m->pf_temp) * (fabs(m->pf_alpha) + fabs(m->pf_beta) * 16.0 + fabs(m->pf_omega) + fabs(m->pf_eps));
     const bool shortcut = xmax < 600.0;
-    std::vector<GrpRec> multi;
     std::vector<int32_t> pconst(std::max(m->n_pair, 1), 0);
-    for (int g = 0; g < m->n_grp; ++g) {
-      const int a = m->grp_ent_ptr[g], b = m->grp_ent_ptr[g + 1];
-      double sumd = 0.0;
-      for (int e = a; e < b; ++e) sumd = (e == a) ? m->ent_dist[e] : sumd + m->ent_dist[e];
-      if (b - a == 1 && shortcut) {
-        if (ent_pair[a] >= 0) pconst[ent_pair[a]] = 1;
-        continue;
-      }
-      if (b - a < 1) continue;
-      GrpRec G{};
-      G.n = b - a;
-      G.allphys = m->grp_allphys[g];
-      for (int e = a; e < b; ++e) {
-        GrpEnt& E = G.e[e - a];
-        E.link = m->ent_link[e];
-        E.pair = ent_pair[e];
-        E.rev = E.sep = 0; E.area32 = 1.0f; E.vf = E.kc = 0.0; E.length = 1.0;
-        if (E.link >= 0) {
-          if (E.link >= L) { pedn_destroy(s); return fail(nullptr, PEDN_E_ARG, "ent_link out of range"); }
-          E.rev = m->link_rev[E.link]; E.sep = m->link_sep[E.link];
-          E.area32 = (float)(m->link_length[E.link] * m->link_width[E.link]);
-          E.vf = m->link_vf[E.link]; E.kc = m->link_kc[E.link]; E.length = m->link_length[E.link];
-        }
-        E.dist_term = (m->pf_alpha * m->ent_dist[e]) / (sumd + 1e-6);
-      }
-      multi.push_back(G);
-    }
-    v.n_multi = (int)multi.size();
-    TRY(upload(s, multi.data(), multi.size(), &v.grp_rec));
-    {  // constant products read the shared row of ones (row n_pair of ent_p) instead of a row of their own
-      std::vector<int32_t> prow(std::max(m->n_pair, 1), 0);
-      for (int q = 0; q < m->n_pair; ++q) prow[q] = pconst[q] ? m->n_pair : q;
-      TRY(upload(s, prow.data(), prow.size(), &v.pair_row));
-    }
+    for (int g = 0; g < m->n_grp; ++g)
+      if (m->grp_ent_ptr[g + 1] - m->grp_ent_ptr[g] == 1 && shortcut && ent_pair[m->grp_ent_ptr[g]] >= 0) pconst[ent_pair[m->grp_ent_ptr[g]]] = 1;
     s->h_pair_const = pconst;
     s->h_turn_pair_ptr.assign(m->turn_pair_ptr, m->turn_pair_ptr + m->n_turns + 1);
     s->h_turn_mode.assign(std::max(m->n_turns, 1), 0);
@@ -326,9 +323,151 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       for (int q = m->turn_pair_ptr[tn]; q < m->turn_pair_ptr[tn + 1]; ++q) all_const = all_const && pconst[q];
       s->h_turn_mode[tn] = all_const ? 1 : 0;
     }
-    std::vector<TurnRec> trec(std::max(m->n_turns, 1));
-    for (int tn = 0; tn < m->n_turns; ++tn) trec[tn] = TurnRec{m->turn_pair_ptr[tn], m->turn_pair_ptr[tn + 1], s->h_turn_mode[tn], 0};
-    TRY(upload(s, trec.data(), trec.size(), &v.turn_rec));
+    // row (incoming slot) of its node every softmax group belongs to, read off its products: the product (od, up, down) is
+    // summed into the turn (up, down) (path_finder.py:668-686); a group none of whose entries feeds a product is never needed
+    std::vector<int> grp_row(std::max(m->n_grp, 1), -1);
+    for (int g = 0; g < m->n_grp; ++g) {
+      const int n = m->grp_node[g];
+      if (n < 0 || n >= N || g < m->node_grp_ptr[n] || g >= m->node_grp_ptr[n + 1]) {
+        pedn_destroy(s);
+        return fail(nullptr, PEDN_E_ARG, "grp_node / node_grp_ptr inconsistent");
+      }
+      const int d = m->node_slot_ptr[n + 1] - m->node_slot_ptr[n];
+      for (int e = m->grp_ent_ptr[g]; e < m->grp_ent_ptr[g + 1]; ++e) {
+        if (ent_pair[e] < 0) continue;
+        const int tn = (int)(std::upper_bound(m->turn_pair_ptr, m->turn_pair_ptr + m->n_turns + 1, ent_pair[e]) - m->turn_pair_ptr) - 1;
+        const int row = (tn - m->node_turn_ptr[n]) / (d - 1);
+        if (tn < m->node_turn_ptr[n] || tn >= m->node_turn_ptr[n + 1] || (grp_row[g] >= 0 && grp_row[g] != row)) {
+          pedn_destroy(s);
+          return fail(nullptr, PEDN_E_ARG, "products of one softmax group lie in different rows");
+        }
+        grp_row[g] = row;
+      }
+    }
+    // Rows (incoming slots) of dynamic nodes.  A row whose turns are all mode 1 (every product constant) has fractions that
+    // depend on the OD weights only: tabulated and renormalised on the host (tabulate_pair_pod), SlotRec.dyn = 2.  The others
+    // get one record each for turn_frac_kernel -- see pedn_types.hpp for the word layout -- and SlotRec.dyn = 1.
+    struct Row { int node, i, cost, need, groups; };
+    std::vector<Row> rows;
+    s->h_slot_dyn.assign(n_slots, 0);
+    for (int n = 0; n < N; ++n) {
+      if (m->node_kind[n] != 1 || !m->node_dyn[n]) continue;
+      const int d = m->node_slot_ptr[n + 1] - m->node_slot_ptr[n];
+      for (int i = 0; i < d; ++i) {
+        const int ta = m->node_turn_ptr[n] + i * (d - 1), tb = ta + d - 1;
+        int need = 0;
+        for (int q = m->turn_pair_ptr[ta]; q < m->turn_pair_ptr[tb]; ++q) need += pconst[q] ? 0 : 1;
+        s->h_slot_dyn[m->node_slot_ptr[n] + i] = need ? 1 : 2;
+        if (!need) continue;
+        int cost = m->turn_pair_ptr[tb] - m->turn_pair_ptr[ta], groups = 0;
+        for (int g = m->node_grp_ptr[n]; g < m->node_grp_ptr[n + 1]; ++g)
+          if (grp_row[g] == i && (m->grp_ent_ptr[g + 1] - m->grp_ent_ptr[g] > 1 || !shortcut)) ++groups;
+        cost += 16 * groups;  // a group costs two divisions and an exp per downstream
+        rows.push_back(Row{n, i, cost, need, groups});
+      }
+    }
+    // workgroups of four rows, heaviest first (they start first); the rows of a workgroup share its PEDN_TF_LDS_ROWS LDS rows
+    std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.cost > b.cost; });
+    std::vector<Row> packed;
+    std::vector<int> lds_base;
+    {
+      std::vector<char> taken(rows.size(), 0);
+      for (size_t a0 = 0; a0 < rows.size(); ++a0) {
+        if (taken[a0]) continue;
+        if (rows[a0].groups > PEDN_TF_COOP_GROUPS) {  // a workgroup of its own: four records of the same row (coop)
+          taken[a0] = 1;
+          for (int k = 0; k < 4; ++k) { packed.push_back(rows[a0]); lds_base.push_back(0); }
+          continue;
+        }
+        int fill = 0, cnt = 0;
+        for (size_t k = a0; k < rows.size() && cnt < 4; ++k) {
+          if (taken[k] || rows[k].groups > PEDN_TF_COOP_GROUPS) continue;
+          const int need = std::min(rows[k].need, PEDN_TF_LDS_ROWS);
+          if (k != a0 && fill + need > PEDN_TF_LDS_ROWS) continue;
+          taken[k] = 1;
+          packed.push_back(rows[k]);
+          lds_base.push_back(fill);
+          fill += need;
+          ++cnt;
+        }
+        for (; cnt < 4; ++cnt) { packed.push_back(Row{-1, 0, 0, 0, 0}); lds_base.push_back(0); }
+      }
+    }
+    std::vector<int32_t> rwords(std::max<size_t>(packed.size(), 1) * PEDN_TROW_WORDS, 0), gwords;
+    std::vector<int32_t> prow(std::max(m->n_pair, 1), -1);  // product -> where its probability is, -1: the constant 1
+    int n_over = 0, n_multi = 0;  // n_over: rows of ent_p, for probabilities beyond a workgroup's LDS rows
+    auto put_d = [](int32_t* w, double x) { memcpy(w, &x, 8); };
+    auto put_f = [](int32_t* w, float x) { memcpy(w, &x, 4); };
+    for (size_t ri = 0; ri < packed.size(); ++ri) {
+      const int n = packed[ri].node, i = packed[ri].i;
+      int32_t* w = &rwords[ri * PEDN_TROW_WORDS];
+      if (n < 0) { w[0] = -1; continue; }
+      if (ri % 4 != 0 && packed[ri - 1].node == n && packed[ri - 1].i == i) {  // coop: copy of the workgroup's first record
+        std::copy(w - PEDN_TROW_WORDS, w, w);
+        continue;
+      }
+      const int s0 = m->node_slot_ptr[n], d = m->node_slot_ptr[n + 1] - s0;
+      const int ta = m->node_turn_ptr[n] + i * (d - 1);
+      w[0] = d; w[1] = ta; w[2] = n_multi; w[4] = m->turn_pair_ptr[ta]; w[5] = m->turn_pair_ptr[ta + d - 1];
+      for (int jj = 0; jj < d - 1; ++jj) {
+        w[84 + 3 * jj] = m->turn_pair_ptr[ta + jj]; w[85 + 3 * jj] = m->turn_pair_ptr[ta + jj + 1]; w[86 + 3 * jj] = s->h_turn_mode[ta + jj];
+      }
+      std::vector<int> used;  // outgoing slots this row's multi-entry groups refer to
+      int n_prob = 0, n_g = 0, any_sep = 0, over = 0;
+      const int lds_rows = std::min(packed[ri].need, PEDN_TF_LDS_ROWS);
+      for (int g = m->node_grp_ptr[n]; g < m->node_grp_ptr[n + 1]; ++g) {
+        const int a = m->grp_ent_ptr[g], b = m->grp_ent_ptr[g + 1];
+        if (grp_row[g] != i || b - a < 1 || (b - a == 1 && shortcut)) continue;
+        double sumd = 0.0;
+        for (int e = a; e < b; ++e) sumd = (e == a) ? m->ent_dist[e] : sumd + m->ent_dist[e];
+        gwords.resize(gwords.size() + 32, 0);
+        int32_t* G = &gwords[gwords.size() - 32];
+        G[0] = b - a; G[1] = m->grp_allphys[g];
+        for (int k = 0; k < PEDN_MAX_DEGREE - 1; ++k) G[2 + k] = G[9 + k] = -1;
+        for (int e = a; e < b; ++e) {
+          const int k = e - a, l = m->ent_link[e];
+          if (l >= 0) {
+            int slot = -1;
+            for (int j = 0; j < d; ++j)
+              if (l < L && m->slot_out_link[s0 + j] == l) slot = j;
+            if (slot < 0) { pedn_destroy(s); return fail(nullptr, PEDN_E_ARG, "softmax entry is not an outgoing link of its node"); }
+            size_t u = std::find(used.begin(), used.end(), slot) - used.begin();
+            if (u == used.size()) used.push_back(slot);
+            G[2 + k] = (int)u;
+          }
+          if (ent_pair[e] >= 0) {
+            if (n_prob < lds_rows) G[9 + k] = lds_base[ri] + n_prob;
+            else { G[9 + k] = PEDN_TF_LDS_ROWS + n_over++; over = 1; }
+            ++n_prob;
+            prow[ent_pair[e]] = G[9 + k];
+          }
+          put_d(&G[16 + 2 * k], (m->pf_alpha * m->ent_dist[e]) / (sumd + 1e-6));
+        }
+        ++n_g; ++n_multi;
+      }
+      if (used.size() > (size_t)(PEDN_MAX_DEGREE - 1)) { pedn_destroy(s); return fail(nullptr, PEDN_E_ARG, "a row refers to more than 7 downstream links"); }
+      for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
+        const int slot = used.empty() ? -1 : used[e < (int)used.size() ? e : 0];
+        int32_t* E = e < 5 ? &w[8 + 10 * e] : &w[64 + 10 * (e - 5)];
+        const int l = slot >= 0 ? m->slot_out_link[s0 + slot] : 0;  // only rows with groups come here, and L > 0 then
+        E[0] = l; E[1] = m->link_rev[l]; E[2] = m->link_sep[l];
+        put_f(&E[3], (float)(m->link_length[l] * m->link_width[l]));
+        put_d(&E[4], m->link_vf[l]); put_d(&E[6], m->link_kc[l]); put_d(&E[8], m->link_length[l]);
+        if (slot >= 0 && E[2]) any_sep = 1;
+      }
+      w[3] = n_g; w[6] = (int)used.size(); w[7] = any_sep; w[107] = over; w[108] = packed[ri].groups > PEDN_TF_COOP_GROUPS;
+    }
+    gwords.resize(gwords.size() + 8 * 32, 0);  // turn_frac_body reads a chunk of four records ahead; padding has n = 0
+    rows = packed;
+    v.n_multi = n_multi;
+    v.n_trow = (int)rows.size();
+    s->n_over = n_over;
+    s->dbg_rwords = rwords; s->dbg_gwords = gwords; s->dbg_prow = prow;
+    TRY(upload(s, rwords.data(), rwords.size(), &v.trow_words));
+    TRY(upload(s, gwords.data(), gwords.size(), &v.tgrp_words));
+    TRY(upload(s, prow.data(), prow.size(), &v.pair_row));
+    for (int q = 0; q < m->n_pair; ++q)
+      if (!pconst[q] && prow[q] < 0) { pedn_destroy(s); return fail(nullptr, PEDN_E_ARG, "(turn, od) product without a softmax entry on a dynamic node"); }
     v.n_turns = m->n_turns;
   }
   TRY(upload(s, m->od_w, (size_t)m->n_od * v.T1, &v.od_w));
@@ -343,26 +482,13 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     v.n_pairs_corr = (int)cr.size();
     TRY(upload(s, cr.data(), cr.size(), &v.corr_rec));
   }
-  {  // bin nodes into blocks of 8 waves: first-fit over the nodes ordered by (row-sum length, slot count) decreasing.
-    // The 8 waves of a block meet at two barriers, so a block lasts as long as its slowest wave; the slow waves are the
-    // rows of dynamic nodes that sum many (turn, od) products one dependent load after the other.  Packing those nodes
-    // into the same (and the first-launched) blocks keeps every other block short.
-    std::vector<int> order(N), cost(N, 0);
+  {  // bin nodes into blocks of 8 waves: first-fit over the nodes ordered by slot count decreasing, so that every block is
+    // full regardless of node degree.  The 8 waves of a block meet at two barriers; since the route-choice sums moved to
+    // turn_frac_kernel every slot wave costs about the same.
+    std::vector<int> order(N);
     for (int n = 0; n < N; ++n) order[n] = n;
     auto deg = [&](int n) { return m->node_slot_ptr[n + 1] - m->node_slot_ptr[n]; };
-    for (int n = 0; n < N; ++n) {
-      if (m->node_kind[n] != 1 || !m->node_dyn[n]) continue;
-      const int d = deg(n);
-      for (int k = 0; k < d; ++k) {
-        int iters = 0;
-        for (int j = 0; j < d - 1; ++j) {
-          const int tn = m->node_turn_ptr[n] + k * (d - 1) + j;
-          if (!s->h_turn_mode[tn]) iters += (m->turn_pair_ptr[tn + 1] - m->turn_pair_ptr[tn] + 7) / 8;
-        }
-        cost[n] = std::max(cost[n], iters);
-      }
-    }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] != cost[b] ? cost[a] > cost[b] : deg(a) > deg(b); });
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return deg(a) > deg(b); });
     std::vector<std::vector<int>> bins;
     std::vector<int> fill;
     for (int n : order) {
@@ -383,7 +509,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         for (int k = 0; k < d; ++k) {
           SlotRec& R = rec[b * 8 + wave++];
           R.node = n; R.slot = k; R.base = base; R.m = d;
-          R.kind = m->node_kind[n]; R.dyn = m->node_dyn[n];
+          R.kind = m->node_kind[n]; R.dyn = s->h_slot_dyn[m->node_slot_ptr[n] + k];
           R.lin = m->slot_in_link[m->node_slot_ptr[n] + k];
           R.lout = m->slot_out_link[m->node_slot_ptr[n] + k];
           R.turn0 = m->node_turn_ptr[n];
@@ -394,17 +520,13 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       }
     }
     s->n_blocks = (int)bins.size();
-    // latency-bound where many junctions sum route-choice products, throughput-bound otherwise (node_kernel comment).
-    // Measured at 6 / 8 waves: delft (989 non-constant products) 39.9 / 36.6 us, 45_intersections (42) 15.5 / 15.9,
-    // nine_intersections (66) 10.4 / 11.3, melbourne (0) 26.4 / 28.0.  PEDN_NODE_WAVES=6|8 overrides.
-    int nonconst = 0;
-    for (int q = 0; q < m->n_pair; ++q) nonconst += s->h_pair_const[q] ? 0 : 1;
-    s->node_waves = nonconst >= 256 ? 8 : 6;
-    if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = atoi(w) == 8 ? 8 : 6;
-    // One launch for the link update of t and the turn probabilities of t+1 saves the fixed cost of a launch (45_intersections
-    // x 2048: 30.7 -> 26.5 us per step) but the fused probabilities re-derive num_pedestrians from the flows (48 instead of
-    // 16 bytes per entry): with many groups the separate launch is as fast (delft x 1024: 59.9 fused, 58.4 separate).
-    s->fuse_tp = (size_t)v.n_multi * v.RS <= (size_t)131072;
+    // register budget of node_kernel: compiled for 8 waves per SIMD (64 VGPRs, a few SGPR spills) or for 6 (measured: delft 32.6
+    // against 35.0 us, melbourne 25.8 against 27.1); PEDN_NODE_WAVES=6|8 overrides
+    s->node_waves = 8;
+    if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = atoi(w) == 6 ? 6 : 8;
+    // The link update of t and the turning fractions of t+1 share one launch (both only read what node_kernel(t) and earlier
+    // launches wrote); PEDN_FUSE_TP=0 gives the fractions a launch of their own in front of node_kernel(t+1).
+    s->fuse_tp = 1;
     if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
     TRY(upload(s, rec.data(), rec.size(), &v.slot_rec));
@@ -423,7 +545,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     HIP_TRY(s, hipMemset(v.sepnp, 0, std::max<size_t>((size_t)L * RS, 1) * sizeof(double)));
     TRY(dalloc(s, (size_t)m->n_turns * RS, &v.tf));
     TRY(dalloc(s, (size_t)m->n_demand * T1 * RS, &v.demand));
-    TRY(dalloc(s, ((size_t)m->n_pair + 1) * RS, &v.ent_p));  // [n_pair] probabilities + the row of ones
+    TRY(dalloc(s, (size_t)std::max(s->n_over, 1) * RS, &v.ent_p));  // probabilities that do not fit a node's LDS rows
+    for (int k = 0; k < 2; ++k) TRY(dalloc(s, (size_t)std::max(m->n_turns, 1) * RS, &v.tfd[k]));
     TRY(dalloc(s, (size_t)m->n_pair * T1, &s->d_pair_pod));
     v.pair_pod = s->d_pair_pod;
     TRY(dalloc(s, (size_t)std::max(m->n_turns, 1) * T1, &s->d_turn_tab));
@@ -461,7 +584,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
                          (int)rows, (size_t)0, (size_t)1, v.RS, 0, v.RS, 0, 1);
       HIP_TRY(s, hipStreamSynchronize(s->stream));
     }
-    if (m->n_pair) HIP_TRY(s, hipMemsetAsync(v.ent_p, 0, (size_t)m->n_pair * v.RS * 8, s->stream));  // not the row of ones
+    HIP_TRY(s, hipMemsetAsync(v.ent_p, 0, (size_t)std::max(s->n_over, 1) * v.RS * 8, s->stream));
+    for (int k = 0; k < 2; ++k) HIP_TRY(s, hipMemsetAsync(v.tfd[k], 0, (size_t)std::max(m->n_turns, 1) * v.RS * 8, s->stream));
     // replica-uniform shortcuts: everything starts uniform; dynamic nodes always use their per-replica rows
     const double qnan = __builtin_nan("");
     s->h_front_u.assign(m->front_gate0, m->front_gate0 + L);
@@ -505,6 +629,7 @@ int pedn_reset(pedn_sim* s) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   HIP_TRY(s, hipSetDevice(s->device));
   s->tp_ready = -1;
+  s->last_t = -1;
   return reset_state(s);
 }
 
@@ -624,6 +749,9 @@ int pedn_set_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, const
   if (n != b - a) return fail(s, PEDN_E_ARG, "turning-fraction count does not match m(m-1)");
   int rc = push_rows(s, s->v.tf, tf, n, (size_t)a, 1, replica);
   if (rc != PEDN_OK) return rc;
+  // a dynamic node recomputes its fractions every step (network.py:272-275); until then a read returns what was imposed
+  s->h_tf_set_epoch[node] = s->step_epoch;
+  if (s->h_node_dyn[node] && s->last_t >= 0 && (rc = push_rows(s, s->v.tfd[s->last_t & 1], tf, n, (size_t)a, 1, replica)) != PEDN_OK) return rc;
   for (int k = 0; k < n; ++k)
     s->h_tf_u[a + k] = (replica == PEDN_ALL && !s->h_node_dyn[node]) ? tf[k] : __builtin_nan("");
   return push_uniform(s);
@@ -637,7 +765,17 @@ int pedn_get_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, doubl
   if (n != b - a) return fail(s, PEDN_E_ARG, "turning-fraction count does not match m(m-1)");
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
-  HIP_TRY(s, hipMemcpy2D(tf, 8, s->v.tf + (size_t)a * s->v.RS + replica, (size_t)s->v.RS * 8, 8, n, hipMemcpyDeviceToHost));
+  const double* src = (s->h_node_dyn[node] && s->last_t >= 0) ? s->v.tfd[s->last_t & 1] : s->v.tf;
+  HIP_TRY(s, hipMemcpy2D(tf, 8, src + (size_t)a * s->v.RS + replica, (size_t)s->v.RS * 8, 8, n, hipMemcpyDeviceToHost));
+  if (s->h_node_dyn[node] && s->last_t >= 0 && s->h_tf_set_epoch[node] != s->step_epoch) {  // rows tabulated on the host (SlotRec.dyn == 2)
+    const int s0 = s->h_node_slot_ptr[node], d = s->h_node_slot_ptr[node + 1] - s0;
+    for (int i = 0; i < d; ++i)
+      if (s->h_slot_dyn[s0 + i] == 2)
+        for (int jj = 0; jj < d - 1; ++jj) {
+          const int tn = a + i * (d - 1) + jj;
+          tf[tn - a] = s->v.pod_pr ? s->h_ttab_r[(size_t)tn * s->v.R + replica] : s->h_ttab[(size_t)s->last_t * s->n_turns + tn];
+        }
+  }
   return PEDN_OK;
 }
 
@@ -706,22 +844,22 @@ static node_kernel_fn node_kernel_for(const pedn_sim* s) {
 static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe = -1, bool* observed = nullptr) {
   DevView& v = s->v;
   const unsigned rgroups = (unsigned)(v.RS / 64);
-  const bool groups = v.n_multi > 0, fused = groups && s->fuse_tp;
+  const bool groups = v.n_trow > 0, fused = groups && s->fuse_tp;
   const bool obs_fused = observe >= 0 && s->rl_ready && s->fuse_obs;
   auto launch = [&](auto kernel, dim3 grid, dim3 block, int e, auto... args) {
     if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, s->stream, ev[e], ev[e + 1], 0, args...);
     else hipLaunchKernelGGL(kernel, grid, block, 0, s->stream, args...);
   };
   if (groups && s->tp_ready != t) {  // first step of an episode, a repeated or an out-of-order step
-    const unsigned nb = (unsigned)(((size_t)v.n_multi * v.RS + 255) / 256);
-    if (v.pr) launch(turn_prob_kernel<true>, dim3(nb), dim3(256), 0, v, t);
-    else launch(turn_prob_kernel<false>, dim3(nb), dim3(256), 0, v, t);
+    const unsigned nb = (unsigned)((v.n_trow + 3) / 4) * rgroups;  // one wave per (row of a dynamic node, 64 replicas)
+    if (v.pr) launch(turn_frac_kernel<true>, dim3(nb), dim3(256), 0, v, t);
+    else launch(turn_frac_kernel<false>, dim3(nb), dim3(256), 0, v, t);
     s->tp_ran = 1;
   }
   launch(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 2, v, t);
   const unsigned nlb = v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2) + 255) / 256) : 0u;
   if (fused || obs_fused) {
-    const unsigned ntb = fused ? (unsigned)(((size_t)v.n_multi * v.RS + 255) / 256) : 0u;
+    const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;
     const unsigned nob = obs_fused ? (unsigned)s->rl.n_agents * rgroups : 0u;  // one block per (agent, 64 replicas)
     RlView q = s->rl;
     if (!obs_fused) q.n_agents = 0;
@@ -739,6 +877,8 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     else launch(link_kernel, dim3(nlb), dim3(256), 4, v, t);
   }
   if (observed) *observed = obs_fused;
+  s->last_t = t;
+  ++s->step_epoch;
   return PEDN_OK;
 }
 
@@ -767,7 +907,7 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   ms[0] = ms[1] = ms[2] = 0.0f;
   if (s->tp_ran) HIP_TRY(s, hipEventElapsedTime(&ms[0], ev[0], ev[1]));  // stand-alone turn probabilities (normally fused into [2])
   HIP_TRY(s, hipEventElapsedTime(&ms[1], ev[2], ev[3]));
-  if (v.n_pairs_corr > 0 || v.n_multi > 0) HIP_TRY(s, hipEventElapsedTime(&ms[2], ev[4], ev[5]));
+  if (v.n_pairs_corr > 0 || v.n_trow > 0) HIP_TRY(s, hipEventElapsedTime(&ms[2], ev[4], ev[5]));
   for (int i = 0; i < 6; ++i) hipEventDestroy(ev[i]);
   return PEDN_OK;
 }
@@ -899,6 +1039,7 @@ int pedn_set_od_weights_per_replica(pedn_sim* s, const double* w) {
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   DevView& v = s->v;
+  s->tp_ready = -1;
   if (!w) {
     v.pod_pr = 0;
     return PEDN_OK;
@@ -921,7 +1062,9 @@ int pedn_set_od_weights_per_replica(pedn_sim* s, const double* w) {
       for (int q = s->h_turn_pair_ptr[tn]; q < s->h_turn_pair_ptr[tn + 1]; ++q) acc += 1.0 * pod[(size_t)q * R + r];
       tab[(size_t)tn * R + r] = acc;
     }
+    finish_tabulated_rows(s, &tab[r], (size_t)R);
   }
+  s->h_ttab_r = tab;
   int rc;
   if (!s->d_pair_pod_r) {
     if ((rc = dalloc(s, (size_t)np * v.RS, &s->d_pair_pod_r)) || (rc = dalloc(s, (size_t)std::max(nt, 1) * v.RS, &s->d_turn_tab_r))) return rc;
@@ -1084,8 +1227,20 @@ int pedn_device_math(int32_t device, int32_t op, int32_t n, const double* a, con
 
 }  // extern "C"
 
+extern "C" int pedn_debug_words(pedn_sim* s, int which, int32_t* out, int n) {
+  const std::vector<int32_t>& w = which == 0 ? s->dbg_rwords : which == 1 ? s->dbg_gwords : s->dbg_prow;
+  for (int i = 0; i < n && i < (int)w.size(); ++i) out[i] = w[i];
+  return (int)w.size();
+}
+
 #ifdef PEDN_PHASE_PROFILE
 // profiling build only (make phase-profile): read (zero = 0) or clear (zero = 1) the 16 phase accumulators of node_kernel
+extern "C" int pedn_debug_tphases(unsigned long long* out, int zero) {
+  void* dev = nullptr;
+  if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_tphase)) != hipSuccess) return -1;
+  if (zero) return (int)hipMemset(dev, 0, sizeof(unsigned long long) * 4096 * 8);
+  return (int)hipMemcpy(out, dev, sizeof(unsigned long long) * 4096 * 8, hipMemcpyDeviceToHost);
+}
 extern "C" int pedn_debug_phases(unsigned long long* out, int zero) {
   const size_t n = (size_t)PEDN_PHASE_WAVES * 12;
   void* dev = nullptr;

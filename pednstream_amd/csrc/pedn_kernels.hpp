@@ -2,10 +2,11 @@
 // Included once by pedn_hip.hip (single translation unit, compiled with -ffp-contract=off).
 //
 // Kernels per step t (reference network.py:266-287):
-//   turn_prob_kernel  one lane per (multi-entry softmax group, replica): P(down | up, od)       path_finder.py:561-589
+//   turn_frac_kernel  one workgroup per (dynamic node, 64 replicas): logit route choice -> the node's turning fractions
+//                                                                                      path_finder.py:561-737
 //   node_kernel       one wave per (node slot, 64 replicas), one block per bin of nodes with <= 8 slots in total:
-//                     sending flow of the slot's incoming link, receiving flow of its outgoing link, dynamic turning
-//                     fractions, the node's flow distribution through LDS, cumulative counts
+//                     sending flow of the slot's incoming link, receiving flow of its outgoing link, the node's flow
+//                     distribution through LDS, cumulative counts
 //                                                                 node.py:164-221,230-242,272-300; link.py:216-416
 //   link_kernel       one lane per (corridor = link pair, two replicas): pedestrians, density, fundamental diagram,
 //                     travel time and its moving average                                link.py:133-188; functions.py:112-134
@@ -13,6 +14,8 @@
 #pragma once
 #include "pedn_math.hpp"
 #include "pedn_types.hpp"
+
+#include <type_traits>
 
 using namespace pedn;
 
@@ -22,8 +25,11 @@ using namespace pedn;
 #define PEDN_PHASE_WAVES (1 << 17)
 __device__ unsigned long long g_phase[PEDN_PHASE_WAVES * 12];  // [wave of the grid][phase]: plain stores, no contended atomics
 #define PH(i, dep) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) : "v"(dep) : "memory"); ph[i] = _t; } while (0)
+__device__ unsigned long long g_tphase[4096 * 8];  // turn_frac_body: [row][stamp] of replica group 0
+#define TPH(i, dep) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) : "v"(dep) : "memory"); tph[i] = _t; } while (0)
 #else
 #define PH(i, dep)
+#define TPH(i, dep)
 #endif
 
 __device__ __forceinline__ size_t at(int t, int col, int cols, int RS, int r) {
@@ -164,80 +170,336 @@ __device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int
 }
 
 // ------------------------------------------------------------------------------------------------- kernels
-// P(down | up, od) of step t for every softmax group with more than one downstream (update_node_turn_probs,
-// path_finder.py:561-589).  A group with a single downstream has P = e/e = 1 exactly; those are constants, never recomputed.
-// One lane per (group, replica).  FUSED: the lane runs inside link_turn_kernel next to the link update of step t-1, which has
-// not stored num_pedestrians[t-1] / density[t-1] yet -- they are recomputed here from [t-2] and the flows of t-1 with the
-// arithmetic of the link update (link.py:133-136), so the two parts of that launch do not depend on each other.
+// wave-uniform values out of a per-lane register: a record is fetched with ONE vector load (lane k holds its k-th word)
+// and its fields are broadcast with v_readlane.  A chain of scalar loads would wait for each record in turn; vector loads
+// return in order and can be issued a record ahead.
+__device__ __forceinline__ int rdl(int x, int k) { return __builtin_amdgcn_readlane(x, k); }
+__device__ __forceinline__ float rdl_f(int x, int k) { return __int_as_float(rdl(x, k)); }
+__device__ __forceinline__ double rdl_d(int x, int k) { return __hiloint2double(rdl(x, k + 1), rdl(x, k)); }
+// a wave-uniform value as a per-lane one the compiler cannot see through: conditions on it become v_cmp / v_cndmask
+// instead of scalar branches, which would cut a block of independent arithmetic chains into pieces that run one after the other
+__device__ __forceinline__ int as_vector(int x) {
+  int y;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(y) : "s"(x));
+  return y;
+}
+
+// Turning fractions of step t for one row (= incoming slot) of one dynamic node and 64 replicas, by ONE wave
+// (PathFinder.calculate_node_turning_fractions, path_finder.py:717-737).  Every softmax group (od, up) and every turn
+// (up, down) belongs to exactly one row, so rows are independent and the wave never meets a barrier:
+//   phase 1  density and capacity of the outgoing links the row's groups refer to (update_node_turn_probs :565-579) --
+//            one batch of independent loads, kept in registers
+//   phase 2  P(down | up, od) of every group with more than one downstream (:580-589) into the wave's share of the block's
+//            LDS rows (lane-private; rows that do not fit go to ent_p); a group with a single downstream has P = e/e = 1
+//            exactly and is never evaluated.  Four groups are evaluated side by side in straight-line code: one group is a
+//            chain of ~40 dependent binary64 operations and a table look-up, and a junction of delft has 24 of them in a row
+//   phase 3  tf[turn] = sum over the turn's (od) products P(down | up, od) * P(od | up) in the reference's order (:668-686),
+//            check_fractions of the row (:691-715), into tfd[t & 1]
+// Only rows with at least one such group come here; a row whose products are all constant has replica-independent
+// fractions that the host tabulates per step (tabulate_pair_pod) and node_kernel reads with scalar loads.
+// (Inside node_kernel the rows that sum ~50 products were the slowest waves of their block and of the launch: 24 % of a
+// wave's lifetime on delft was the barrier behind them.)  P(od | up) is replica independent (:599-615), tabulated per
+// (step, product) on the host.  Row record, group records and product tables arrive by vector loads (see rdl).
+// FUSED: the wave runs inside link_turn_kernel next to the link update of step t-1, which has not stored
+// num_pedestrians[t-1] / density[t-1] yet -- they are recomputed here from [t-2] and the flows of t-1 with the arithmetic of
+// the link update (link.py:133-136), so the parts of that launch do not depend on each other.
 template <bool PR, bool FUSED>
-__device__ __forceinline__ void turn_prob_body(const DevView& v, int t, size_t gid) {
+__device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned block) {
+  __shared__ double sP[PEDN_TF_LDS_ROWS * 64];
+  __shared__ double sAcc[(PEDN_MAX_DEGREE - 1) * 64];  // coop rows: the turns' sums on their way to wave 0
+  constexpr int NE = PEDN_MAX_DEGREE - 1;
   const int RS = v.RS;
-  int gi = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
-  int r = (int)(gid % (size_t)RS);
-  if (gi >= v.n_multi) return;
-  const GrpRec& G = v.grp_rec[gi];  // wave-uniform: scalar loads
+  const unsigned rgroups = (unsigned)(RS / 64);
+  const int lane = (int)(threadIdx.x & 63);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int row = (int)(block / rgroups) * 4 + wave;
+  const int r = (int)(block % rgroups) * 64 + lane;
+  if (row >= v.n_trow) return;  // wave-uniform; no barrier below
+  const int* rw = v.trow_words + (size_t)row * PEDN_TROW_WORDS;
+  const int w0 = rw[lane], w1 = rw[64 + lane];
+  const int m = rdl(w0, 0), turn0 = rdl(w0, 1), grp0 = rdl(w0, 2), n_grp = rdl(w0, 3), Q0 = rdl(w0, 4), Q1 = rdl(w0, 5);
+  const int n_used = rdl(w0, 6), any_sep = rdl(w0, 7), overflow = rdl(w1, 43), coop = rdl(w1, 44), part = coop ? wave : 0;
+  if (m < 0) return;  // padding record of a block with fewer than four rows
+#ifdef PEDN_PHASE_PROFILE
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  TPH(0, w0 + w1);
+#endif
   uint32_t fl = 0;
-  const int n = G.n, allphys = G.allphys;
   const int t2 = wrap_idx(t - 2, v.T1, fl);
-  auto peds = [&](int l) -> float {  // num_pedestrians[t-1]
-    if (!FUSED) return v.f32[G_N][at(t - 1, l, v.L, RS, r)];
-    const double d = v.f64[F_IN][at(t - 1, l, v.Lall, RS, r)] - v.f64[F_OUT][at(t - 1, l, v.Lall, RS, r)];
-    return (float)((double)v.f32[G_N][at(t - 2, l, v.L, RS, r)] + d);
+  const bool ppr = v.pod_pr != 0;  // per-replica OD weights: tables indexed [product][replica] instead of [step][product]
+  // ---- everything whose address is known now, issued together: tabulated turns, first chunk of the product tables, first
+  // pair of group records, and (below) the phase-1 history values
+  const int* gw = v.tgrp_words + (size_t)grp0 * 32;  // padded: reading a pair of records ahead stays in bounds
+  int gcur = gw[(size_t)part * 64 + lane];
+  const int nq = Q1 - Q0;
+  const double* pod = v.pair_pod + (size_t)t * v.n_pair + Q0;
+  int pcode = lane < nq ? v.pair_row[Q0 + lane] : -1;
+  double pw = (lane < nq && !ppr) ? pod[lane] : 0.0;
+  const double ttab = lane < m - 1 ? (ppr ? 0.0 : v.turn_tab[(size_t)t * v.n_turns + turn0 + lane]) : 0.0;
+
+  // ---- phase 1
+  float kf[NE];
+  double cap[NE];
+  auto entry = [&](int e, int& link, int& rev, int& sep, float& area32, double& vf, double& kc, double& length) {
+    const int ww = e < 5 ? w0 : w1, b = e < 5 ? 8 + 10 * e : 10 * (e - 5);
+    link = rdl(ww, b); rev = rdl(ww, b + 1); sep = rdl(ww, b + 2); area32 = rdl_f(ww, b + 3);
+    vf = rdl_d(ww, b + 4); kc = rdl_d(ww, b + 6); length = rdl_d(ww, b + 8);
   };
-  double cap[PEDN_MAX_DEGREE - 1];
-  float kf[PEDN_MAX_DEGREE - 1];
-  double sumc = 0.0;
+  // E0..E1: a compile-time range of entries, loaded unconditionally (entries >= n_used repeat entry 0 in the record): the
+  // compiler issues the whole batch before the first use.  SEP: some entry is a separator link.
+  auto batch = [&](auto e0_t, auto e1_t, auto sep_t) {
+    constexpr int E0 = decltype(e0_t)::value, E1 = decltype(e1_t)::value;
+    constexpr bool SEP = decltype(sep_t)::value;
+    float n_l[E1 - E0], n_r[E1 - E0], k_l[E1 - E0];
+    double d_l[E1 - E0], d_r[E1 - E0], c_l[E1 - E0], sw[E1 - E0], snp[E1 - E0];
 #pragma unroll
-  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
-    if (e < n) {
-      const GrpEnt& E = G.e[e];
-      if (E.link >= 0) {
-        if (E.sep) {  // Separator.get_density = density[t-1], link.py:427-428
-          if (!FUSED) kf[e] = v.f32[G_K][at(t - 1, E.link, v.L, RS, r)];
-          else {
-            const float na = peds(E.link);
-            const double w = v.sepw[(size_t)E.link * RS + r];
-            kf[e] = v.sepnp[(size_t)E.link * RS + r] != 0.0 ? (float)((double)na / (E.length * w)) : na / (float)(E.length * w);
-          }
-        } else kf[e] = (peds(E.link) + peds(E.rev)) / E.area32;
-        double c = v.f64[F_R][at(t2, E.link, v.L, RS, r)];
-        if (!(c >= 0.0)) {
-          const double vf = PR ? v.vf_r[(size_t)E.link * RS + r] : E.vf, kc = PR ? v.kc_r[(size_t)E.link * RS + r] : E.kc;
-          c = v.back[(size_t)E.link * RS + r] * vf * kc * v.dt;  // :575-576
+    for (int e = E0; e < E1; ++e) {
+      int link, rev, sep; float area32; double vf, kc, length;
+      entry(e, link, rev, sep, area32, vf, kc, length);
+      const int i = e - E0;
+      if (!FUSED) {
+        n_l[i] = v.f32[G_N][at(t - 1, link, v.L, RS, r)];
+        n_r[i] = v.f32[G_N][at(t - 1, rev, v.L, RS, r)];
+        if (SEP) k_l[i] = v.f32[G_K][at(t - 1, link, v.L, RS, r)];
+      } else {
+        n_l[i] = v.f32[G_N][at(t - 2, link, v.L, RS, r)];
+        n_r[i] = v.f32[G_N][at(t - 2, rev, v.L, RS, r)];
+        d_l[i] = v.f64[F_IN][at(t - 1, link, v.Lall, RS, r)] - v.f64[F_OUT][at(t - 1, link, v.Lall, RS, r)];
+        d_r[i] = v.f64[F_IN][at(t - 1, rev, v.Lall, RS, r)] - v.f64[F_OUT][at(t - 1, rev, v.Lall, RS, r)];
+        if (SEP) { sw[i] = v.sepw[(size_t)link * RS + r]; snp[i] = v.sepnp[(size_t)link * RS + r]; }
+      }
+      c_l[i] = v.f64[F_R][at(t2, link, v.L, RS, r)];
+    }
+#pragma unroll
+    for (int e = E0; e < E1; ++e) {
+      int link, rev, sep; float area32; double vf, kc, length;
+      entry(e, link, rev, sep, area32, vf, kc, length);
+      const int i = e - E0;
+      float pl = n_l[i], pr = n_r[i];
+      if (FUSED) { pl = (float)((double)pl + d_l[i]); pr = (float)((double)pr + d_r[i]); }  // num_pedestrians[t-1], link.py:133-135
+      float k = (pl + pr) / area32;  // Link.get_density, link.py:190-197
+      if (SEP && sep) {              // Separator.get_density = density[t-1], link.py:427-428
+        if (!FUSED) k = k_l[i];
+        else k = snp[i] != 0.0 ? (float)((double)pl / (length * sw[i])) : pl / (float)(length * sw[i]);
+      }
+      double c = c_l[i];
+      if (!(c >= 0.0)) {  // no receiving flow recorded yet: back_gate_width * v_f * k_c * dt (:575-576)
+        const double vfr = PR ? v.vf_r[(size_t)link * RS + r] : vf, kcr = PR ? v.kc_r[(size_t)link * RS + r] : kc;
+        c = v.back[(size_t)link * RS + r] * vfr * kcr * v.dt;
+      }
+      kf[e] = k;
+      cap[e] = c;
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I4 = std::integral_constant<int, 4>;
+  using I7 = std::integral_constant<int, NE>;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) { kf[e] = 0.0f; cap[e] = 0.0; }
+  if (any_sep) batch(I0{}, I4{}, std::true_type{});
+  else batch(I0{}, I4{}, std::false_type{});
+  if (n_used > 4) {  // junctions with more than five arms
+    if (any_sep) batch(I4{}, I7{}, std::true_type{});
+    else batch(I4{}, I7{}, std::false_type{});
+  }
+  TPH(1, kf[0] + kf[1] + kf[2] + kf[3] + (float)(cap[0] + cap[1] + cap[2] + cap[3]) + (float)(gcur + pcode) + (float)(pw + ttab));
+  // ---- phase 2
+  auto put_prob = [&](int q, double p) {
+    if (q >= PEDN_TF_LDS_ROWS) v.ent_p[(size_t)(q - PEDN_TF_LDS_ROWS) * RS + r] = p;
+    else if (q >= 0) sP[q * 64 + lane] = p;
+  };
+  auto pick = [&](int idx, float& k, double& c) {  // entry idx of the row record, -1: virtual link (:577-579)
+    k = 0.0f;
+    c = 100.0;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      k = idx == u ? kf[u] : k;
+      c = idx == u ? cap[u] : c;
+    }
+  };
+  // the two groups of one record pair x NE_ entries as ONE straight-line block (no branch before the stores): their divisions,
+  // exp chains and table look-ups overlap.  Absent groups / entries (e >= n) run on harmless values and are discarded.
+  auto eval_pair = [&](auto ne_t, int gv, int na, int nb) {
+    constexpr int NE_ = decltype(ne_t)::value;
+    double ce[2][NE_], ex[2][NE_], xx[2][NE_], sumc[2], esum[2], p[2][NE_];
+    float ke[2][NE_];
+    bool any_special = false;
+    const int nav = as_vector(na), nbv = as_vector(nb);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = h * 32, n = h ? nbv : nav;
+#pragma unroll
+      for (int e = 0; e < NE_; ++e) pick(as_vector(rdl(gv, b + 2 + e)), ke[h][e], ce[h][e]);
+      sumc[h] = ce[h][0];
+#pragma unroll
+      for (int e = 1; e < NE_; ++e) { const double s2 = sumc[h] + ce[h][e]; sumc[h] = e < n ? s2 : sumc[h]; }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = h * 32, n = h ? nbv : nav;
+      const int allphys = as_vector(rdl(gv, b + 1));
+#pragma unroll
+      for (int e = 0; e < NE_; ++e) {
+        // (x - 2)+ / 8 in float32 when every downstream is a physical link, else in binary64 (:581,583); a division by 8 is
+        // the multiplication by 0.125, bit for bit
+        float xf = ke[h][e] - 2.0f;
+        if (!(xf > 0.0f)) xf = 0.0f;
+        double xd = (double)ke[h][e] - 2.0;
+        if (!(xd > 0.0)) xd = 0.0;
+        const double nd = allphys ? (double)((float)v.pf_beta * (xf * 0.125f)) : v.pf_beta * (xd * 0.125);
+        const double u = rdl_d(gv, b + 16 + 2 * e) + nd - (v.pf_omega * ce[h][e]) / (sumc[h] + 1e-6) + v.pf_eps;
+        xx[h][e] = e < n ? -v.pf_temp * u : -1.0;
+        bool sp;
+        ex[h][e] = pedn_exp_main(xx[h][e], sp);
+        any_special = any_special || sp;
+      }
+    }
+    if (any_special) {  // |x| < 2^-54 or >= 512: the full function (rare)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < NE_; ++e) ex[h][e] = pedn_exp(xx[h][e]);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = h ? nbv : nav;
+      esum[h] = ex[h][0];
+#pragma unroll
+      for (int e = 1; e < NE_; ++e) { const double s2 = esum[h] + ex[h][e]; esum[h] = e < n ? s2 : esum[h]; }
+#pragma unroll
+      for (int e = 0; e < NE_; ++e) p[h][e] = ex[h][e] / esum[h];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int b = h * 32, n = h ? nb : na;
+#pragma unroll
+      for (int e = 0; e < NE_; ++e)
+        if (e < n) put_prob(rdl(gv, b + 9 + e), p[h][e]);
+    }
+  };
+  auto eval_slow = [&](int gv, int b, int n) {  // any group size
+    const int allphys = rdl(gv, b + 1);
+    double ce[NE], ex[NE];
+    float ke[NE];
+    double sumc = 0.0, esum = 0.0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (e < n) {
+        pick(rdl(gv, b + 2 + e), ke[e], ce[e]);
+        sumc = (e == 0) ? ce[e] : sumc + ce[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (e < n) {
+        double nd;
+        if (allphys) {
+          float x = ke[e] - 2.0f;
+          if (!(x > 0.0f)) x = 0.0f;
+          nd = (double)((float)v.pf_beta * (x / 8.0f));
+        } else {
+          double x = (double)ke[e] - 2.0;
+          if (!(x > 0.0)) x = 0.0;
+          nd = v.pf_beta * (x / 8.0);
         }
-        cap[e] = c;
-      } else {
-        kf[e] = 0.0f;
-        cap[e] = 100.0;  // :577-579
+        const double u = rdl_d(gv, b + 16 + 2 * e) + nd - (v.pf_omega * ce[e]) / (sumc + 1e-6) + v.pf_eps;
+        ex[e] = pedn_exp(-v.pf_temp * u);
+        esum = (e == 0) ? ex[e] : esum + ex[e];
       }
-      sumc = (e == 0) ? cap[e] : sumc + cap[e];
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+      if (e < n) put_prob(rdl(gv, b + 9 + e), ex[e] / esum);
+  };
+  // pairs of groups: this wave takes every `pstep`-th pair from `part` on (a row with many groups is shared out over the
+  // four waves of its workgroup: coop)
+  const int n_pairs = (n_grp + 1) / 2, pstep = coop ? 4 : 1;
+  for (int pi = part; pi < n_pairs; pi += pstep) {
+    const int gnext = pi + pstep < n_pairs ? gw[(size_t)(pi + pstep) * 64 + lane] : 0;
+    // the record behind the row's last group belongs to another row: size 0, evaluated on harmless values, nothing stored
+    const int na = rdl(gcur, 0), nb = 2 * pi + 1 < n_grp ? rdl(gcur, 32) : 0;
+    const int nmax = max(na, nb);
+    if (nmax <= 2 && !(v.dbg & 1)) eval_pair(std::integral_constant<int, 2>{}, gcur, na, nb);
+    else if (nmax <= 3 && !(v.dbg & 1)) eval_pair(std::integral_constant<int, 3>{}, gcur, na, nb);
+    else { eval_slow(gcur, 0, na); eval_slow(gcur, 32, nb); }
+    gcur = gnext;
+  }
+  TPH(2, lane);
+  // ---- phase 3
+  if (coop) __syncthreads();  // workgroup-uniform: the four waves hold the same row
+  double* out = v.tfd[t & 1];
+  int chunk0 = 0;  // products [chunk0, chunk0 + 64) of the row are in pcode / pw
+  auto prob_of = [&](int code) -> double {
+    return code < 0 ? 1.0 : code < PEDN_TF_LDS_ROWS ? sP[code * 64 + lane] : v.ent_p[(size_t)(code - PEDN_TF_LDS_ROWS) * RS + r];
+  };
+  auto turn_sum = [&](int jj) -> double {
+    const int tq0 = rdl(w1, 20 + 3 * jj) - Q0, tq1 = rdl(w1, 21 + 3 * jj) - Q0, mode = rdl(w1, 22 + 3 * jj);
+    double acc = 0.0;
+    if (mode) {
+      acc = ppr ? v.turn_tab_r[(size_t)(turn0 + jj) * RS + r] : __hiloint2double(rdl(__double2hiint(ttab), jj), rdl(__double2loint(ttab), jj));
+    } else if (!ppr && !overflow && nq <= 64 && !(v.dbg & 2)) {
+      // every probability is the constant 1 or in LDS: four products per pass, no branch in between
+      auto lds_prob = [&](int q) -> double {
+        const int c = rdl(pcode, q);
+        const double e = sP[(c < 0 ? 0 : c) * 64 + lane];
+        return c < 0 ? 1.0 : e;
+      };
+      int q = tq0;
+      for (; q + 4 <= tq1; q += 4) {
+        double e[4], w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          e[k] = lds_prob(q + k);
+          w[k] = __hiloint2double(rdl(__double2hiint(pw), q + k), rdl(__double2loint(pw), q + k));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += e[k] * w[k];
+      }
+      for (; q < tq1; ++q) acc += lds_prob(q) * __hiloint2double(rdl(__double2hiint(pw), q), rdl(__double2loint(pw), q));
+    } else {
+      for (int q = tq0; q < tq1; ++q) {
+        if (q < chunk0 || q >= chunk0 + 64) {  // rows with more than 64 products: another chunk of the tables
+          chunk0 = q;
+          pcode = chunk0 + lane < nq ? v.pair_row[Q0 + chunk0 + lane] : -1;
+          pw = (chunk0 + lane < nq && !ppr) ? pod[chunk0 + lane] : 0.0;
+        }
+        const int code = rdl(pcode, q - chunk0);
+        const double w = ppr ? v.pair_pod_r[(size_t)(Q0 + q) * RS + r]
+                             : __hiloint2double(rdl(__double2hiint(pw), q - chunk0), rdl(__double2loint(pw), q - chunk0));
+        acc += prob_of(code) * w;
+      }
+    }
+    return acc;
+  };
+  double rowsum = 0.0;
+  if (coop) {  // the turns shared out over the waves, their sums handed to wave 0 through LDS
+    for (int jj = part; jj < m - 1; jj += 4) sAcc[jj * 64 + lane] = turn_sum(jj);
+    __syncthreads();
+    if (part != 0) return;
+    for (int jj = 0; jj < m - 1; ++jj) {
+      const double acc = sAcc[jj * 64 + lane];
+      out[(size_t)(turn0 + jj) * RS + r] = acc;
+      rowsum = (jj == 0) ? acc : rowsum + acc;
+    }
+  } else {
+    for (int jj = 0; jj < m - 1; ++jj) {
+      const double acc = turn_sum(jj);
+      out[(size_t)(turn0 + jj) * RS + r] = acc;
+      rowsum = (jj == 0) ? acc : rowsum + acc;
     }
   }
-  double ex[PEDN_MAX_DEGREE - 1];
-  double esum = 0.0;
-#pragma unroll
-  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
-    if (e < n) {
-      double nd;
-      if (allphys) {  // float32 array branch of :581,583
-        float x = kf[e] - 2.0f;
-        if (!(x > 0.0f)) x = 0.0f;
-        nd = (double)((float)v.pf_beta * (x / 8.0f));
-      } else {
-        double x = (double)kf[e] - 2.0;
-        if (!(x > 0.0)) x = 0.0;
-        nd = v.pf_beta * (x / 8.0);
-      }
-      double u = G.e[e].dist_term + nd - (v.pf_omega * cap[e]) / (sumc + 1e-6) + v.pf_eps;
-      ex[e] = pedn_exp(-v.pf_temp * u);
-      esum = (e == 0) ? ex[e] : esum + ex[e];
-    }
+  TPH(3, rowsum);
+#ifdef PEDN_PHASE_PROFILE
+  if (block % rgroups == 0 && lane == 0 && row < 4096) {
+    for (int i = 0; i < 3; ++i) g_tphase[row * 8 + i] += tph[i + 1] - tph[i];
+    g_tphase[row * 8 + 4] += 1;
+    g_tphase[row * 8 + 5] = n_grp; g_tphase[row * 8 + 6] = nq; g_tphase[row * 8 + 7] = tph[0];
   }
-#pragma unroll
-  for (int e = 0; e < PEDN_MAX_DEGREE - 1; ++e) {
-    if (e < n) {
-      const int q = G.e[e].pair;  // slot of the (turn, od) product that consumes this probability
-      if (q >= 0) v.ent_p[(size_t)q * RS + r] = ex[e] / esum;
+#endif
+  if (fabs(rowsum - 1) > 1e-3) {  // check_fractions, :700-714
+    for (int jj = 0; jj < m - 1; ++jj) {
+      const double f = out[(size_t)(turn0 + jj) * RS + r];
+      out[(size_t)(turn0 + jj) * RS + r] = rowsum > 1e-6 ? f / rowsum : 1.0 / (double)(m - 1);
     }
   }
   if (fl) atomicOr(&v.flags[r], fl);
@@ -245,8 +507,8 @@ __device__ __forceinline__ void turn_prob_body(const DevView& v, int t, size_t g
 
 // stand-alone launch: first step of an episode, or a step that does not follow the previous one
 template <bool PR>
-__global__ __launch_bounds__(256, 8) void turn_prob_kernel(DevView v, int t) {
-  turn_prob_body<PR, false>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+__global__ __launch_bounds__(256) void turn_frac_kernel(DevView v, int t) {
+  turn_frac_body<PR, false>(v, t, blockIdx.x);
 }
 
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
@@ -283,62 +545,20 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     lin = W.lin;
     lout = W.lout;
     const int turn0 = W.turn0 + slot * (m - 1);
-    const bool static_tf = kind == 1 && !W.dyn;
-    // (called after the flows: run before them, next to the batch of history loads, the kernel took 67 us instead of 39 on
-    // delft x 1024 -- its waits drain the whole batch first)
-    auto dyn_row = [&]() {
-        // tf[turn] = sum over the turn's (od) products P(down | up, od) * P(od | up)   (path_finder.py:668-686), in the
-        // reference's order.  P(od | up) is replica independent (:599-615) and tabulated per product and step on the host;
-        // P(down | up, od) was stored in product order by turn_prob_kernel, constant ones share one row of ones.  Products
-        // are taken eight at a time: eight independent loads, then the eight dependent adds (a row of a busy junction sums
-        // up to ~50 products; one dependent load per add made such rows the slowest waves of the launch).  The row is kept
-        // in the wave's own row of the LDS tile, so the turn loop is a real loop.
-        const double* pod = v.pair_pod + (size_t)t * v.n_pair;
-        const bool ppr = v.pod_pr != 0;  // per-replica OD weights: tables indexed [product][replica] instead of [step][product]
-        double rowsum = 0.0;
-        for (int jj = 0; jj < m - 1; ++jj) {
-          const TurnRec T = v.turn_rec[turn0 + jj];
-          double acc = 0.0;
-          if (T.mode) {
-            acc = ppr ? v.turn_tab_r[(size_t)(turn0 + jj) * RS + r] : v.turn_tab[(size_t)t * v.n_turns + turn0 + jj];
-          } else {
-            for (int q = T.q0; q < T.q1; q += 8) {
-              double e[8], w[8];
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const int qi = q + i < T.q1 ? q + i : T.q1 - 1;  // past the end: re-read the last product, weight 0
-                e[i] = v.ent_p[(size_t)v.pair_row[qi] * RS + r];
-                w[i] = ppr ? v.pair_pod_r[(size_t)qi * RS + r] : pod[qi];
-              }
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                const double term = q + i < T.q1 ? e[i] * w[i] : 0.0;  // acc + 0.0 == acc: acc is a sum of non-negative terms
-                acc += term;
-              }
-            }
-          }
-          const int j = jj < slot ? jj : jj + 1;
-          sPS[(size_t)(base + slot * m + j) * 64 + lane] = acc;
-          rowsum = (jj == 0) ? acc : rowsum + acc;
-        }
-        const bool renorm = fabs(rowsum - 1) > 1e-3;  // check_fractions, :700-714
-        for (int jj = 0; jj < m - 1; ++jj) {
-          const int j = jj < slot ? jj : jj + 1;
-          double f = sPS[(size_t)(base + slot * m + j) * 64 + lane];
-          if (renorm) f = rowsum > 1e-6 ? f / rowsum : 1.0 / (double)(m - 1);
-          v.tf[(size_t)(turn0 + jj) * RS + r] = f;
-          sPS[(size_t)(base + slot * m + j) * 64 + lane] = f;
-        }
-    };
+    // turning fractions of row `slot` (SlotRec.dyn): imposed / default ones from tf or the replica-uniform shortcut tf_u; those
+    // of a dynamic node (path_finder.py:591-715) from the buffer turn_frac_kernel filled for this step, or -- every product of
+    // the row constant -- from the host's per-step table.  Part of the load batch below.
+    const double* tfrow = W.dyn == 1 ? v.tfd[t & 1] : (W.dyn == 2 ? v.turn_tab_r : v.tf);
+    const double* tfu = W.dyn == 2 ? v.turn_tab + (size_t)t * v.n_turns : v.tf_u;
+    const bool tf_shared = W.dyn == 2 ? v.pod_pr == 0 : (W.dyn == 0 && tfu[turn0] == tfu[turn0]);  // tf_u: NaN = per-replica rows
     if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
       s_i = v.demand[((size_t)W.demand_row * v.T1 + tp) * RS + r];
       co_prev = rowp(v.f64[F_CO], tp, lin, Lall, RS, r0)[lane];
       ci_prev = rowp(v.f64[F_CI], tp, lout, Lall, RS, r0)[lane];
-      if (static_tf) {
-        const bool shared = v.tf_u[turn0] == v.tf_u[turn0];  // not NaN
+      if (kind == 1) {
 #pragma unroll
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
-          if (jj < m - 1) tfr[jj] = shared ? v.tf_u[turn0 + jj] : v.tf[(size_t)(turn0 + jj) * RS + r];
+          if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
       }
       r_i = 1e6;
     } else {
@@ -368,11 +588,10 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       x.back_out = bu == bu ? bu : v.back[(size_t)lout * RS + r];
       x.sepw_in = Pin.sep ? v.sepw[(size_t)lin * RS + r] : 0.0;
       x.sepw_out = Pout.sep ? v.sepw[(size_t)lout * RS + r] : 0.0;
-      if (static_tf) {
-        const bool shared = v.tf_u[turn0] == v.tf_u[turn0];  // not NaN
+      if (kind == 1) {
 #pragma unroll
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
-          if (jj < m - 1) tfr[jj] = shared ? v.tf_u[turn0 + jj] : v.tf[(size_t)(turn0 + jj) * RS + r];
+          if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
       }
       if (!Pin.sep) x.k_in = x.n_in / (float)(Pin.length * Pin.width);
       co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
@@ -389,21 +608,12 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     if (s_i < 0.0 || r_i < 0.0) fl |= PEDN_F_NEG_FLOW;
 
     if (kind == 1) {
-      // turning fractions of row `slot`: static, or recomputed from the route-choice tables (path_finder.py:591-715)
-      if (W.dyn) {
-        dyn_row();
-        for (int jj = 0; jj < m - 1; ++jj) {  // P[i][j] * s_i  (node.py:285)
-          const int j = jj < slot ? jj : jj + 1;
-          sPS[(size_t)(base + slot * m + j) * 64 + lane] *= s_i;
-        }
-      } else {
-        // P[i][j] * s_i  (node.py:285)
+      // P[i][j] * s_i  (node.py:285)
 #pragma unroll
-        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
-          if (jj < m - 1) {
-            const int j = jj < slot ? jj : jj + 1;
-            sPS[(size_t)(base + slot * m + j) * 64 + lane] = tfr[jj] * s_i;
-          }
+      for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
+        if (jj < m - 1) {
+          const int j = jj < slot ? jj : jj + 1;
+          sPS[(size_t)(base + slot * m + j) * 64 + lane] = tfr[jj] * s_i;
         }
       }
     } else {
@@ -777,20 +987,22 @@ __global__ __launch_bounds__(256) void rl_observe_kernel(DevView v, RlView q, in
 }
 
 // ONE launch after node_kernel(t) for everything that only reads what node_kernel(t) and earlier launches wrote:
-//   blocks [0, n_link)              the link update of step t
-//   blocks [n_link, n_link + n_tp)  the turn probabilities of step t+1 (models with softmax groups)
+//   blocks [0, n_tp)                the turning fractions of step t+1 (models with dynamic nodes)
+//   blocks [n_tp, n_tp + n_link)    the link update of step t
 //   the remaining blocks            observations and rewards of step t for the batched RL env (q.n_agents > 0)
 // The parts are independent (the second and third re-derive what the first is about to store), so they run side by side;
 // as separate launches each of them cost 5-9 us, most of it the fixed cost of a launch.
 // (OBS = false: the instantiation ordinary stepping uses carries neither the LDS nor the registers of the third part)
 template <bool PR, bool OBS>
 __global__ __launch_bounds__(256) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, RlView q, int accumulate) {
-  if (blockIdx.x < n_link_blocks) {
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the turning-fraction workgroups come first in dispatch order: theirs are the long dependent chains of the launch (the
+  // heaviest rows lead), the link update behind them is bound by memory throughput and fills the machine around them
+  if (blockIdx.x < n_tp_blocks) {
+    turn_frac_body<PR, true>(v, t + 1, blockIdx.x);
+  } else if (blockIdx.x < n_tp_blocks + n_link_blocks) {
+    const size_t gid = (size_t)(blockIdx.x - n_tp_blocks) * blockDim.x + threadIdx.x;
     if (PR) link_pr_body(v, t, gid);
     else link_body(v, t, gid);
-  } else if (blockIdx.x < n_link_blocks + n_tp_blocks) {
-    turn_prob_body<PR, true>(v, t + 1, (size_t)(blockIdx.x - n_link_blocks) * blockDim.x + threadIdx.x);
   } else if (OBS) {
     rl_observe_body<true>(v, q, t, accumulate, blockIdx.x - n_link_blocks - n_tp_blocks);
   }
@@ -801,7 +1013,6 @@ __global__ void init_state_kernel(DevView v) {
   const int RS = v.RS, L = v.L, T1 = v.T1;
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)T1 * L * RS;
-  if (gid < (size_t)RS) v.ent_p[(size_t)v.n_pair * RS + gid] = 1.0;  // the row constant products read
   if (gid >= total) return;
   int r = (int)(gid % RS);
   int l = (int)((gid / RS) % L);

@@ -101,14 +101,11 @@ __device__ const uint64_t kExpTab[128][2] = {
 #include "exp_table.inc"
 };
 
-__device__ inline double pedn_exp(double x) {
-  uint32_t abstop = (uint32_t)(d2u(x) >> 52) & 0x7ffu;
-  if (abstop - 0x3c9u >= 0x3fu) {
-    if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;
-    if (x != x) return x;
-    if (abstop >= 0x409u) return (d2u(x) >> 63) ? 0.0 : __longlong_as_double(0x7ff0000000000000ll);
-    return exp(x);  // 512 <= |x| < 1024: not reachable from the softmax, not bit-pinned
-  }
+// main path of pedn_exp without its branches: valid when `special` comes back false (2^-54 <= |x| < 512); several of these in
+// a row stay one straight-line block, so their table look-ups and dependent chains overlap
+__device__ __forceinline__ double pedn_exp_main(double x, bool& special) {
+  const uint32_t abstop = (uint32_t)(d2u(x) >> 52) & 0x7ffu;
+  special = abstop - 0x3c9u >= 0x3fu;
   const double InvLn2N = 0x1.71547652b82fep+7, Shift = 0x1.8p52, NegLn2hiN = -0x1.62e42fefa0000p-8, NegLn2loN = -0x1.cf79abc9e3b3ap-47;
   const double C2 = 0x1.ffffffffffdbdp-2, C3 = 0x1.555555555543cp-3, C4 = 0x1.55555cf172b91p-5, C5 = 0x1.1111167a4d017p-7;
   double kd = fma(x, InvLn2N, Shift);
@@ -122,6 +119,18 @@ __device__ inline double pedn_exp(double x) {
   double tmp = fma(r2 * r2, fma(r, C5, C4), fma(fma(r, C3, C2), r2, tail + r));
   double scale = u2d(sbits);
   return fma(scale, tmp, scale);
+}
+
+__device__ inline double pedn_exp(double x) {
+  uint32_t abstop = (uint32_t)(d2u(x) >> 52) & 0x7ffu;
+  if (abstop - 0x3c9u >= 0x3fu) {
+    if (abstop - 0x3c9u >= 0x80000000u) return 1.0 + x;
+    if (x != x) return x;
+    if (abstop >= 0x409u) return (d2u(x) >> 63) ? 0.0 : __longlong_as_double(0x7ff0000000000000ll);
+    return exp(x);  // 512 <= |x| < 1024: not reachable from the softmax, not bit-pinned
+  }
+  bool special;
+  return pedn_exp_main(x, special);
 }
 
 // ---- RNG contract -----------------------------------------------------------------------------------------------

@@ -18,6 +18,8 @@ struct LinkP {  // static per-link parameters, wave-uniform on the device
 };
 
 struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything static it needs, fetched by ONE scalar load burst
+  // dyn: where the slot's row of turning fractions comes from -- 0 tf / tf_u (default or imposed), 1 tfd[t & 1] (turn_frac_kernel),
+  // 2 turn_tab[t] / turn_tab_r (every product constant: replica-independent, tabulated and renormalised on the host)
   int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, pad0, pad1;
   LinkP Pin, Pout;  // parameters of the incoming / outgoing link of the slot (unused for a virtual pair)
 };
@@ -27,32 +29,33 @@ struct CorrRec {  // one lane group of link_kernel: both directions of a corrido
   LinkP Pa, Pb;
 };
 
-struct TurnRec {  // one turn of a dynamic node: its (turn, od) products and how its fraction is obtained
-  int32_t q0, q1;  // products [q0, q1) in the reference's summation order
-  int32_t mode;    // 1: every product is constant -> the raw fraction is tabulated per step on the host
-  int32_t pad;
-};
-
-struct GrpEnt {  // one downstream entry of a softmax group (update_node_turn_probs, path_finder.py:561-589)
-  int32_t link, rev, sep;  // outgoing link (-1: virtual), its reverse, separator flag
-  int32_t pair;            // the (turn, od) product that consumes this entry's probability (-1: none)
-  float area32;            // float32(length * width) of a plain link
-  int32_t pad;
-  double vf, kc;           // for the capacity fallback back_gate * v_f * k_c * dt (:576)
-  double dist_term;        // alpha * distance / (sum of the group's distances + 1e-6), static (:582)
-  double length;           // of the link (density of a separator = pedestrians / (length * separator width))
-};
-
-struct GrpRec {  // one softmax group with more than one downstream: everything static a lane of turn_prob_kernel needs,
-  int32_t n, allphys, pad0, pad1;  // fetched by one scalar load burst at an address that depends on blockIdx only
-  GrpEnt e[PEDN_MAX_DEGREE - 1];
-};
+// ---- route choice (path_finder.py:561-737), organised per row (= incoming slot) of a dynamic node: one wave of
+// turn_frac_kernel owns (row, 64 replicas).  Its static data are int32 word records fetched with vector loads (lane k holds
+// word k) and broadcast with v_readlane -- see turn_frac_body.
+#define PEDN_TF_LDS_ROWS 64    // LDS rows (64 lanes x 8 bytes) of one workgroup = 4 rows of dynamic nodes, shared out by the host
+#define PEDN_TROW_WORDS 128
+#define PEDN_TF_COOP_GROUPS 4   // rows with more multi-entry groups get a workgroup of their own (see turn_frac_body)
+// row record, PEDN_TROW_WORDS words (m = -1: padding):
+//   [0] m  [1] first turn of the row  [2] first group (index into tgrp_words / 32)  [3] number of multi-entry groups
+//   [4] Q0  [5] Q1: the row's (turn, od) products  [6] n_used outgoing links below  [7] some of them is a separator
+//   entries e = 0..4 at 8 + 10 e, e = 5, 6 at 64 + 10 (e - 5): link, reverse link, separator flag, float32(length * width),
+//       free-flow speed (2 words), k_critical (2), length (2); entries >= n_used repeat entry 0
+//   turns jj = 0..6 at 84 + 3 jj: q0, q1 (absolute product indices), mode (1: every product is the constant 1 -> the raw
+//       fraction is tabulated per step on the host)
+//   [107] 1: some probability of the row lives in ent_p instead of LDS
+//   [108] 1: coop -- the four records of this workgroup are the same row; its groups and turns are shared out over the waves
+// group record, 32 words (softmax group (od, up) with more than one downstream, update_node_turn_probs :561-589):
+//   [0] n  [1] allphys  [2 + e] entry of the row record the downstream link is (-1: virtual link, density 0, capacity 100)
+//   [9 + e] where P(down | up, od) goes: < 0 nowhere, < PEDN_TF_LDS_ROWS that LDS row of the workgroup, else row
+//   (value - PEDN_TF_LDS_ROWS) of ent_p   [16 + 2 e] alpha * distance / (sum of the group's distances + 1e-6) (2 words)
 
 struct DevView {
   double* f64[7];
   float* f32[6];
   float* rsum;
   double *front, *back, *sepw, *sepnp, *tf, *demand, *ent_p;
+  double* tfd[2];  // [n_turns][RS] x 2: fractions of dynamic nodes; step t reads tfd[t & 1], the fractions of t + 1 are
+                   // written into the other buffer while the host can still read those of t
   // replica-uniform shortcuts (NaN = the value differs between replicas, read the per-replica row instead): a value every
   // replica shares is one scalar load per wave instead of 8 bytes per lane
   const double *front_u, *back_u;  // [L]
@@ -69,13 +72,14 @@ struct DevView {
   const SlotRec* slot_rec;
   const CorrRec* corr_rec;
   const int32_t *node_kind, *node_slot_ptr, *node_turn_ptr, *node_demand_row, *node_dyn, *slot_in, *slot_out;
-  const TurnRec* turn_rec;      // [n_turns]
-  const int32_t* pair_row;      // [n_pair] row of ent_p that holds the product's probability; constant products share the row of ones
-  const GrpRec* grp_rec;        // [n_multi] groups with more than one downstream entry (single-entry groups have P = 1 exactly)
+  const int32_t* pair_row;      // [n_pair] where the product's P(down | up, od) is: -1 the constant 1 (single-entry group), else as word 9 + e of a group record
+  const int32_t* trow_words;    // [n_trow][PEDN_TROW_WORDS] rows of dynamic nodes, heaviest first
+  const int32_t* tgrp_words;    // [n_multi + 8][32] groups with more than one downstream entry (single-entry groups have P = 1 exactly)
   const double* turn_tab;       // [T+1][n_turns] tabulated raw fractions of such turns
   const double* pair_pod;  // [T+1][n_pair] P(od | up) of the pair's upstream group, replica independent
-  int32_t L, Lall, T1, RS, R, W, n_grp, n_multi, n_pairs_corr, n_pair, n_turns;
+  int32_t L, Lall, T1, RS, R, W, n_grp, n_multi, n_trow, n_pairs_corr, n_pair, n_turns;
   double dt, pf_temp, pf_alpha, pf_beta, pf_omega, pf_eps;
   uint32_t k0, k1, replica_offset;
   int32_t meanfield;
+  int32_t dbg;
 };
