@@ -177,7 +177,6 @@ def main():
     origins = list(net.origin_nodes)
     for k, nid in enumerate(origins):          # one upload per origin: [R, T] rows keyed by the global replica id
         e.set_demand_matrix(net.nodes[nid].index, np.stack([replica_demand(T, offset + r) for r in range(R)]))
-    net._dirty_demand = set()
     e.synchronize()
     L = e.n_links
 

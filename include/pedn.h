@@ -152,6 +152,8 @@ int pedn_set_demand(pedn_sim* sim, int32_t node, int32_t replica, const double* 
 int pedn_get_demand(pedn_sim* sim, int32_t node, int32_t replica, double* values, int32_t n);
 /* the same for every replica in one call: values[r * n + i] = demand of replica r at time index i (n <= T+1, rest zero) */
 int pedn_set_demand_matrix(pedn_sim* sim, int32_t node, const double* values, int32_t n);
+/* the same for a subset: values[k * n + i] = demand of replica replicas[k] at time index i, k < n_rep; one upload */
+int pedn_set_demand_rows(pedn_sim* sim, int32_t node, const int32_t* replicas, int32_t n_rep, const double* values, int32_t n);
 /* values[T+1] -> OD weight row `od` (shared by all replicas) */
 int pedn_set_od_weights(pedn_sim* sim, int32_t od, const double* values, int32_t n);
 int pedn_set_turning_fractions(pedn_sim* sim, int32_t node, int32_t replica, const double* tf, int32_t n);
@@ -226,7 +228,9 @@ typedef struct pedn_rl_desc {
 
 /* validates the description and allocates the device buffers; returns the row lengths */
 int pedn_rl_configure(pedn_sim* sim, const pedn_rl_desc* desc, int32_t* n_actions, int32_t* n_obs);
-/* actions[n_replicas][n_actions] (binary64, widths in metres); on_device != 0: `actions` is a device pointer */
+/* actions[n_replicas][n_actions] (binary64, widths in metres); on_device != 0: `actions` is a device pointer.  A NaN entry
+ * means "no action for this slot": the widths it controls stay exactly as they are (apply_all_actions only touches the agents
+ * it is given, rl/builders.py:343-352) */
 int pedn_rl_apply_actions(pedn_sim* sim, const double* actions, int32_t on_device);
 /* observations and rewards of step t (after pedn_step(t)) into the device buffers; accumulate != 0 adds the rewards to
  * the buffer (float32, like the reference's cumulative_rewards) instead of overwriting.  obs / rewards may be NULL;

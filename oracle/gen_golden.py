@@ -165,7 +165,7 @@ def native_ensemble(case, name, n_runs=64, times=(100, 200, 300, 400, 498)):
 
 
 def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_steps=150, seed=0, replica=0,
-            np_seed=20261003, action_seed=1):
+            np_seed=20261003, action_seed=1, skip_prob=0.0, init_widths=None):
     """Config #5 caller: the reference's ActionApplier / ObservationBuilder / reward (rl/builders.py,
     rl/pz_pednet_env.py:548-581) around network_loading, driven by seeded uniform actions in [-0.5, width + 0.5]
     (so that both clip bounds and the per-step delta limit are exercised)."""
@@ -185,6 +185,8 @@ def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_s
             spec.append({"id": a, "type": "gate", "links": [l.link_id for l in am.get_gater_outgoing_links(a)]})
     rng = np.random.default_rng(action_seed)
     acts, obs_l, rew_l, term_l = [], [], [], []
+    for lid, (attr, w) in (init_widths or {}).items():    # e.g. a separator width outside ActionApplier's clip band
+        setattr(net.links[tuple(int(x) for x in lid.split("_"))], attr, w)
     with rh.InjectedRNG(net, seed=seed, replica=replica) as inj:
         for _ in range(env_steps):
             actions = {}
@@ -196,6 +198,9 @@ def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_s
                 else:
                     ws = [net.links[tuple(int(x) for x in l.split("_"))].width for l in sp["links"]]
                     a = np.array([rng.uniform(-0.5, w + 0.5) for w in ws], dtype=np.float32)
+                if skip_prob and rng.uniform() < skip_prob:     # partial action dict: this agent is not given an action (NaN row)
+                    row.extend([float("nan")] * len(a))
+                    continue
                 actions[sp["id"]] = a
                 row.extend(a.tolist())
             obs, rew, term = env.step(actions)
@@ -206,7 +211,8 @@ def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_s
     state = rh.dump_state(net, steps=env.sim_step)
     extras = {"draws": dict(inj.draws), "steps_run": env.sim_step}
     info = {"scenario": name, "seed": seed, "replica": replica, "mode": "philox", "np_seed": np_seed, "mutations": [],
-            "rl": {"obs_mode": obs_mode, "normalize": normalize, "action_gap": action_gap, "env_steps": env_steps, "agents": spec}}
+            "rl": {"obs_mode": obs_mode, "normalize": normalize, "action_gap": action_gap, "env_steps": env_steps, "agents": spec,
+                   "init_widths": init_widths or {}}}
     state["rl_actions"] = np.array(acts, dtype=np.float32)
     state["rl_obs"] = np.array(obs_l, dtype=np.float32)
     state["rl_rewards"] = np.array(rew_l, dtype=np.float32)
@@ -397,6 +403,9 @@ CASES.update({   # the remaining scenario directories of the reference's data/ (
     "butterfly_scC_full": lambda: scenario_case("butterfly_scC_full", "butterfly_scC", seed=3, replica=3),
     "one_intersection_full": lambda: scenario_case("one_intersection_full", "one_intersection_v0", seed=4, replica=0),
     "two_coordinators_prefix": lambda: scenario_case("two_coordinators_prefix", "two_coordinators", steps=260, seed=5, replica=4),
+    "rl_nine_partial": lambda: rl_case("rl_nine_partial", "nine_intersections", obs_mode="option3", env_steps=150, action_seed=11, skip_prob=0.4),
+    "rl_corridor_partial": lambda: rl_case("rl_corridor_partial", "long_corridor", obs_mode="option1", env_steps=150, action_seed=12, skip_prob=0.5,
+                                           init_widths={"2_3": ("separator_width", 0.75)}),
     "rl_butterfly_opt3": lambda: rl_case("rl_butterfly_opt3", "butterfly_scC", obs_mode="option3", env_steps=200, action_seed=7),
     "rl_one_intersection_opt5": lambda: rl_case("rl_one_intersection_opt5", "one_intersection_v0", obs_mode="option5", env_steps=200, action_seed=8),
 })

@@ -58,8 +58,11 @@ struct pedn_sim {
   std::vector<int32_t> dbg_rwords, dbg_gwords, dbg_prow;
   int last_t = -1;     // last step launched (pedn_get_turning_fractions: which buffer holds a dynamic node's fractions)
   std::vector<void*> allocs;
-  void* stage = nullptr;
-  size_t stage_bytes = 0;
+  // host <-> device staging: two slots used in turn, each a pinned host buffer + a device buffer + the event recorded behind
+  // the slot's last consumer, so that an upload neither waits for the stream nor borrows caller memory beyond the call
+  struct Stage { void* pin = nullptr; void* dev = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; };
+  Stage stage[2];
+  int stage_next = 0;
   std::string err;
 };
 
@@ -97,14 +100,36 @@ static int dalloc(pedn_sim* s, size_t n, T** dst) {
   return PEDN_OK;
 }
 
-static int ensure_stage(pedn_sim* s, size_t bytes) {
-  if (bytes <= s->stage_bytes) return PEDN_OK;
-  if (s->stage) HIP_TRY(s, hipFree(s->stage));
-  s->stage = nullptr;
-  s->stage_bytes = 0;
-  size_t want = std::max<size_t>(bytes, 1 << 20);
-  HIP_TRY(s, hipMalloc(&s->stage, want));
-  s->stage_bytes = want;
+// A staging slot of at least `bytes` whose previous use has completed (the other slot may still be in flight).
+static int stage_acquire(pedn_sim* s, size_t bytes, pedn_sim::Stage** out) {
+  pedn_sim::Stage& st = s->stage[s->stage_next];
+  s->stage_next ^= 1;
+  if (!st.done) HIP_TRY(s, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+  else HIP_TRY(s, hipEventSynchronize(st.done));
+  if (bytes > st.bytes) {
+    if (st.dev) HIP_TRY(s, hipFree(st.dev));
+    if (st.pin) HIP_TRY(s, hipHostFree(st.pin));
+    st.dev = st.pin = nullptr;
+    st.bytes = 0;
+    const size_t want = std::max<size_t>(bytes, 1 << 20);
+    HIP_TRY(s, hipMalloc(&st.dev, want));
+    HIP_TRY(s, hipHostMalloc(&st.pin, want, hipHostMallocDefault));
+    st.bytes = want;
+  }
+  *out = &st;
+  return PEDN_OK;
+}
+
+// host values -> the slot's device buffer (through its pinned buffer: the caller's memory is not touched after the return)
+static int stage_upload(pedn_sim* s, pedn_sim::Stage* st, const void* src, size_t bytes, size_t offset = 0) {
+  memcpy((char*)st->pin + offset, src, bytes);
+  HIP_TRY(s, hipMemcpyAsync((char*)st->dev + offset, (char*)st->pin + offset, bytes, hipMemcpyHostToDevice, s->stream));
+  return PEDN_OK;
+}
+
+// call after the last launch that reads or writes the slot
+static int stage_commit(pedn_sim* s, pedn_sim::Stage* st) {
+  HIP_TRY(s, hipEventRecord(st->done, s->stream));
   return PEDN_OK;
 }
 
@@ -198,6 +223,8 @@ static int push_matrix(pedn_sim* s, T* dst, const T* src, int n_rows) {
 }
 
 extern "C" {
+
+static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows, size_t row0, size_t row_stride, int replica);
 
 int pedn_abi_version(void) { return PEDN_ABI_VERSION; }
 
@@ -558,32 +585,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   {
     const double* w0[3] = {m->front_gate0, m->back_gate0, m->sep_width0};
     double* dst[3] = {v.front, v.back, v.sepw};
-    for (int k = 0; k < 3; ++k) {
-      if (L == 0) break;
-      TRY(ensure_stage(s, (size_t)L * 8));
-      HIP_TRY(s, hipMemcpyAsync(s->stage, w0[k], (size_t)L * 8, hipMemcpyHostToDevice, s->stream));
-      size_t n = (size_t)L * v.RS;
-      hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst[k], (const double*)s->stage, L,
-                         (size_t)0, (size_t)1, v.RS, 0, v.RS, 0, 1);
-      HIP_TRY(s, hipStreamSynchronize(s->stream));
-    }
-    if (m->n_turns) {
-      TRY(ensure_stage(s, (size_t)m->n_turns * 8));
-      HIP_TRY(s, hipMemcpyAsync(s->stage, m->tf_init, (size_t)m->n_turns * 8, hipMemcpyHostToDevice, s->stream));
-      size_t n = (size_t)m->n_turns * v.RS;
-      hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v.tf, (const double*)s->stage,
-                         m->n_turns, (size_t)0, (size_t)1, v.RS, 0, v.RS, 0, 1);
-      HIP_TRY(s, hipStreamSynchronize(s->stream));
-    }
-    if (m->n_demand) {
-      size_t rows = (size_t)m->n_demand * v.T1;
-      TRY(ensure_stage(s, rows * 8));
-      HIP_TRY(s, hipMemcpyAsync(s->stage, m->demand, rows * 8, hipMemcpyHostToDevice, s->stream));
-      size_t n = rows * v.RS;
-      hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v.demand, (const double*)s->stage,
-                         (int)rows, (size_t)0, (size_t)1, v.RS, 0, v.RS, 0, 1);
-      HIP_TRY(s, hipStreamSynchronize(s->stream));
-    }
+    for (int k = 0; k < 3; ++k) TRY(push_rows(s, dst[k], w0[k], L, 0, 1, PEDN_ALL));
+    TRY(push_rows(s, v.tf, m->tf_init, m->n_turns, 0, 1, PEDN_ALL));
+    TRY(push_rows(s, v.demand, m->demand, m->n_demand * v.T1, 0, 1, PEDN_ALL));
     HIP_TRY(s, hipMemsetAsync(v.ent_p, 0, (size_t)std::max(s->n_over, 1) * v.RS * 8, s->stream));
     for (int k = 0; k < 2; ++k) HIP_TRY(s, hipMemsetAsync(v.tfd[k], 0, (size_t)std::max(m->n_turns, 1) * v.RS * 8, s->stream));
     // replica-uniform shortcuts: everything starts uniform; dynamic nodes always use their per-replica rows
@@ -617,7 +621,11 @@ int pedn_destroy(pedn_sim* s) {
   hipSetDevice(s->device);
   if (s->stream) hipStreamSynchronize(s->stream);
   for (void* p : s->allocs) hipFree(p);
-  if (s->stage) hipFree(s->stage);
+  for (pedn_sim::Stage& st : s->stage) {
+    if (st.dev) hipFree(st.dev);
+    if (st.pin) hipHostFree(st.pin);
+    if (st.done) hipEventDestroy(st.done);
+  }
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -639,16 +647,15 @@ static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows,
   DevView& v = s->v;
   if (replica != PEDN_ALL && (replica < 0 || replica >= v.R)) return fail(s, PEDN_E_ARG, "replica out of range");
   HIP_TRY(s, hipSetDevice(s->device));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));  // the staging buffer may still be read by an earlier scatter
-  int rc = ensure_stage(s, (size_t)n_rows * 8);
-  if (rc != PEDN_OK) return rc;
-  HIP_TRY(s, hipMemcpyAsync(s->stage, values, (size_t)n_rows * 8, hipMemcpyHostToDevice, s->stream));
+  pedn_sim::Stage* st;
+  int rc = stage_acquire(s, (size_t)n_rows * 8, &st);
+  if (rc != PEDN_OK || (rc = stage_upload(s, st, values, (size_t)n_rows * 8)) != PEDN_OK) return rc;
   int r0 = replica == PEDN_ALL ? 0 : replica, r1 = replica == PEDN_ALL ? v.RS : replica + 1;
   size_t n = (size_t)n_rows * (r1 - r0);
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst, (const double*)s->stage, n_rows,
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst, (const double*)st->dev, n_rows,
                      row0, row_stride, v.RS, r0, r1, 0, 1);
   HIP_TRY(s, hipGetLastError());
-  return PEDN_OK;
+  return stage_commit(s, st);
 }
 
 int pedn_set_demand(pedn_sim* s, int32_t node, int32_t replica, const double* values, int32_t n) {
@@ -656,7 +663,7 @@ int pedn_set_demand(pedn_sim* s, int32_t node, int32_t replica, const double* va
   if (node < 0 || node >= s->n_nodes) return fail(s, PEDN_E_ARG, "node out of range");
   int row = s->node_demand_row[node];
   if (row < 0) return fail(s, PEDN_E_ARG, "node has no virtual (origin/destination) link");
-  std::vector<double> full(s->v.T1, 0.0);
+  std::vector<double> full(s->v.T1, 0.0);  // copied into the pinned staging buffer before push_rows returns
   for (int i = 0; i < n && i < s->v.T1; ++i) full[i] = values[i];
   return push_rows(s, s->v.demand, full.data(), s->v.T1, (size_t)row * s->v.T1, 1, replica);
 }
@@ -685,16 +692,39 @@ int pedn_set_demand_matrix(pedn_sim* s, int32_t node, const double* values, int3
   if (n < 0 || n > v.T1) return fail(s, PEDN_E_ARG, "more demand values than time indices");
   if (n == 0) return PEDN_OK;
   HIP_TRY(s, hipSetDevice(s->device));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));  // the staging buffer may still be read by an earlier scatter
   const size_t bytes = (size_t)v.R * n * 8;
-  int rc = ensure_stage(s, bytes);
-  if (rc != PEDN_OK) return rc;
-  HIP_TRY(s, hipMemcpyAsync(s->stage, values, bytes, hipMemcpyHostToDevice, s->stream));
+  pedn_sim::Stage* st;
+  int rc = stage_acquire(s, bytes, &st);
+  if (rc != PEDN_OK || (rc = stage_upload(s, st, values, bytes)) != PEDN_OK) return rc;
   const size_t lanes = (size_t)v.T1 * v.RS;
-  hipLaunchKernelGGL(demand_matrix_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s->stream, v.demand, (const double*)s->stage,
+  hipLaunchKernelGGL(demand_matrix_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s->stream, v.demand, (const double*)st->dev,
                      (size_t)row, n, v.T1, v.R, v.RS);
   HIP_TRY(s, hipGetLastError());
-  return PEDN_OK;
+  return stage_commit(s, st);
+}
+
+int pedn_set_demand_rows(pedn_sim* s, int32_t node, const int32_t* replicas, int32_t n_rep, const double* values, int32_t n) {
+  if (!s || !values || !replicas) return fail(s, PEDN_E_ARG, "null argument");
+  if (node < 0 || node >= s->n_nodes) return fail(s, PEDN_E_ARG, "node out of range");
+  const int row = s->node_demand_row[node];
+  if (row < 0) return fail(s, PEDN_E_ARG, "node has no virtual (origin/destination) link");
+  DevView& v = s->v;
+  if (n < 0 || n > v.T1) return fail(s, PEDN_E_ARG, "more demand values than time indices");
+  for (int k = 0; k < n_rep; ++k)
+    if (replicas[k] < 0 || replicas[k] >= v.R) return fail(s, PEDN_E_ARG, "replica out of range");
+  if (n == 0 || n_rep <= 0) return PEDN_OK;
+  HIP_TRY(s, hipSetDevice(s->device));
+  // staging layout: values [n_rep][n] (f64), then the replica ids (int32)
+  const size_t vbytes = (size_t)n_rep * n * 8, bytes = vbytes + (size_t)n_rep * 4;
+  pedn_sim::Stage* st;
+  int rc = stage_acquire(s, bytes, &st);
+  if (rc != PEDN_OK || (rc = stage_upload(s, st, values, vbytes)) != PEDN_OK || (rc = stage_upload(s, st, replicas, (size_t)n_rep * 4, vbytes)) != PEDN_OK)
+    return rc;
+  const size_t lanes = (size_t)v.T1 * n_rep;
+  hipLaunchKernelGGL(demand_rows_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s->stream, v.demand, (const double*)st->dev,
+                     (const int32_t*)((const char*)st->dev + vbytes), n_rep, (size_t)row, n, v.T1, v.RS);
+  HIP_TRY(s, hipGetLastError());
+  return stage_commit(s, st);
 }
 
 int pedn_draw_demand(pedn_sim* s, int32_t node, uint64_t seed, const int32_t* pattern, const double* base, const double* peak,
@@ -709,27 +739,27 @@ int pedn_draw_demand(pedn_sim* s, int32_t node, uint64_t seed, const int32_t* pa
     if (!(base[r] >= 0.0) || !(peak[r] >= 0.0) || base[r] + 2.0 * peak[r] > 500.0) return fail(s, PEDN_E_ARG, "demand rate outside [0, 500]");
   }
   HIP_TRY(s, hipSetDevice(s->device));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));  // the staging buffer may still be read by an earlier launch
   // staging layout: pattern, spike_start, spike_len (int32 [R] each, padded to 8 bytes), then base, peak, spike_height (f64 [R])
   const size_t R = (size_t)v.R, ioff = ((3 * R * 4 + 7) / 8) * 8, bytes = ioff + 3 * R * 8;
-  int rc = ensure_stage(s, bytes);
+  pedn_sim::Stage* st;
+  int rc = stage_acquire(s, bytes, &st);
   if (rc != PEDN_OK) return rc;
-  std::vector<unsigned char> h(bytes);
-  memcpy(h.data(), pattern, R * 4);
-  memcpy(h.data() + R * 4, spike_start, R * 4);
-  memcpy(h.data() + 2 * R * 4, spike_len, R * 4);
-  memcpy(h.data() + ioff, base, R * 8);
-  memcpy(h.data() + ioff + R * 8, peak, R * 8);
-  memcpy(h.data() + ioff + 2 * R * 8, spike_height, R * 8);
-  HIP_TRY(s, hipMemcpy(s->stage, h.data(), bytes, hipMemcpyHostToDevice));
-  const unsigned char* d = (const unsigned char*)s->stage;
+  unsigned char* h = (unsigned char*)st->pin;
+  memcpy(h, pattern, R * 4);
+  memcpy(h + R * 4, spike_start, R * 4);
+  memcpy(h + 2 * R * 4, spike_len, R * 4);
+  memcpy(h + ioff, base, R * 8);
+  memcpy(h + ioff + R * 8, peak, R * 8);
+  memcpy(h + ioff + 2 * R * 8, spike_height, R * 8);
+  HIP_TRY(s, hipMemcpyAsync(st->dev, st->pin, bytes, hipMemcpyHostToDevice, s->stream));
+  const unsigned char* d = (const unsigned char*)st->dev;
   const size_t lanes = (size_t)v.T1 * v.RS;
   hipLaunchKernelGGL(draw_demand_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s->stream, v.demand, (size_t)row, v.T1, v.R,
                      v.RS, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), v.replica_offset, (uint32_t)node,
                      (const int32_t*)d, (const double*)(d + ioff), (const double*)(d + ioff + R * 8), (const int32_t*)(d + R * 4),
                      (const int32_t*)(d + 2 * R * 4), (const double*)(d + ioff + 2 * R * 8));
   HIP_TRY(s, hipGetLastError());
-  return PEDN_OK;
+  return stage_commit(s, st);
 }
 
 int pedn_set_od_weights(pedn_sim* s, int32_t od, const double* values, int32_t n) {
@@ -798,15 +828,15 @@ int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
   if (v.L == 0) return PEDN_OK;
   double* dst = which == PEDN_W_FRONT ? v.front : which == PEDN_W_BACK ? v.back : which == PEDN_W_SEP ? v.sepw : v.sepnp;
   HIP_TRY(s, hipSetDevice(s->device));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
   size_t bytes = (size_t)v.L * v.R * 8;
-  int rc = ensure_stage(s, bytes);
-  if (rc != PEDN_OK) return rc;
-  HIP_TRY(s, hipMemcpyAsync(s->stage, values, bytes, hipMemcpyHostToDevice, s->stream));
+  pedn_sim::Stage* st;
+  int rc = stage_acquire(s, bytes, &st);
+  if (rc != PEDN_OK || (rc = stage_upload(s, st, values, bytes)) != PEDN_OK) return rc;
   size_t n = (size_t)v.L * v.R;
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst, (const double*)s->stage, v.L,
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst, (const double*)st->dev, v.L,
                      (size_t)0, (size_t)1, v.RS, 0, v.R, 1, v.R);
   HIP_TRY(s, hipGetLastError());
+  if ((rc = stage_commit(s, st)) != PEDN_OK) return rc;
   if (which <= PEDN_W_BACK) {
     std::vector<double>& u = which == PEDN_W_FRONT ? s->h_front_u : s->h_back_u;
     for (int l = 0; l < v.L; ++l) {
@@ -953,19 +983,21 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   size_t n = (size_t)(t1 - t0) * (c1 - c0) * (r1 - r0);
   size_t esz = field < 7 ? 8 : 4;
-  int rc = ensure_stage(s, n * esz);
+  pedn_sim::Stage* st;
+  int rc = stage_acquire(s, n * esz, &st);
   if (rc != PEDN_OK) return rc;
   unsigned blocks = (unsigned)((n + 255) / 256);
   if (field < 7)
-    hipLaunchKernelGGL(gather_kernel<double>, dim3(blocks), dim3(256), 0, s->stream, (const double*)v.f64[field], (double*)s->stage, t0,
+    hipLaunchKernelGGL(gather_kernel<double>, dim3(blocks), dim3(256), 0, s->stream, (const double*)v.f64[field], (double*)st->dev, t0,
                        t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS);
   else
-    hipLaunchKernelGGL(gather_kernel<float>, dim3(blocks), dim3(256), 0, s->stream, (const float*)v.f32[field - 7], (float*)s->stage, t0,
+    hipLaunchKernelGGL(gather_kernel<float>, dim3(blocks), dim3(256), 0, s->stream, (const float*)v.f32[field - 7], (float*)st->dev, t0,
                        t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS);
   HIP_TRY(s, hipGetLastError());
-  HIP_TRY(s, hipMemcpyAsync(out, s->stage, n * esz, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipMemcpyAsync(st->pin, st->dev, n * esz, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return PEDN_OK;
+  memcpy(out, st->pin, n * esz);
+  return stage_commit(s, st);
 }
 
 void* pedn_device_ptr(pedn_sim* s, int32_t field, int64_t* columns, int64_t* replica_stride) {

@@ -860,6 +860,7 @@ __global__ void rl_apply_kernel(DevView v, RlView q) {
   const int l = q.agent_links[q.agent_link_ptr[ag] + i];
   const LinkP P = v.lp[l];
   double x = q.actions[(size_t)r * q.A + a];
+  if (x != x) return;  // NaN: this agent was given no action
   if (q.agent_type[ag] == 0) {  // separator: clip_separator_action_value + Separator.separator_width setter (link.py:462-478)
     const double cur = v.sepw[(size_t)l * v.RS + r];
     if (fabs(x - cur) > q.max_delta_sep) x = cur + clip_d(x - cur, -q.max_delta_sep, q.max_delta_sep);
@@ -1058,6 +1059,14 @@ __global__ void demand_matrix_kernel(double* dst, const double* src, size_t row,
   if (gid >= (size_t)T1 * RS) return;
   const int t = (int)(gid / RS), r = (int)(gid % RS);
   dst[(row * T1 + t) * RS + r] = (r < R && t < n) ? src[(size_t)r * n + t] : 0.0;
+}
+
+// demand[row][t][replicas[k]] = src[k][t] for t < n (0 beyond): pedn_set_demand_rows
+__global__ void demand_rows_kernel(double* dst, const double* src, const int32_t* replicas, int n_rep, size_t row, int n, int T1, int RS) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)T1 * n_rep) return;
+  const int t = (int)(gid / n_rep), k = (int)(gid % n_rep);
+  dst[(row * T1 + t) * RS + replicas[k]] = t < n ? src[(size_t)k * n + t] : 0.0;
 }
 
 // pedn_draw_demand: one lane per (time index, replica) of one origin's demand row

@@ -98,6 +98,7 @@ def _load():
         "pedn_destroy": (C.c_int, [P]),
         "pedn_set_demand": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
         "pedn_set_demand_matrix": (C.c_int, [P, C.c_int32, _F64P, C.c_int32]),
+        "pedn_set_demand_rows": (C.c_int, [P, C.c_int32, _I32P, C.c_int32, _F64P, C.c_int32]),
         "pedn_get_demand": (C.c_int, [P, C.c_int32, C.c_int32, _F64P, C.c_int32]),
         "pedn_draw_demand": (C.c_int, [P, C.c_int32, C.c_uint64, _I32P, _F64P, _F64P, _I32P, _I32P, _F64P]),
         "pedn_set_od_weights": (C.c_int, [P, C.c_int32, _F64P, C.c_int32]),
@@ -144,7 +145,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand", "pedn_set_demand_matrix", "pedn_get_demand", "pedn_draw_demand",
+EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand", "pedn_set_demand_matrix", "pedn_set_demand_rows", "pedn_get_demand", "pedn_draw_demand",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
            "pedn_device_ptr", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_rl_configure",
@@ -215,6 +216,14 @@ class Engine:
         if v.ndim != 2 or v.shape[0] != self.n_replicas:
             raise ValueError(f"expected [n_replicas={self.n_replicas}, n], got {v.shape}")
         self._ck(self._lib.pedn_set_demand_matrix(self._h, int(node_index), v.ctypes.data_as(_F64P), v.shape[1]))
+
+    def set_demand_rows(self, node_index, replicas, values):
+        """values [len(replicas), n]: the origin's demand of the listed replicas in one upload."""
+        rep = np.ascontiguousarray(replicas, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.ndim != 2 or v.shape[0] != len(rep):
+            raise ValueError(f"expected [{len(rep)}, n], got {v.shape}")
+        self._ck(self._lib.pedn_set_demand_rows(self._h, int(node_index), rep.ctypes.data_as(_I32P), len(rep), v.ctypes.data_as(_F64P), v.shape[1]))
 
     def draw_demand(self, node_index, seed, pattern, base, peak, spike_start, spike_len, spike_height):
         """Origin demand of every replica drawn on the device (include/pedn.h: pedn_draw_demand); arrays [n_replicas]."""

@@ -378,6 +378,7 @@ class Network:
         self._engine = None
         self._dirty_demand = set()
         self._col_cache = {}
+        self._epoch = 0
 
         self.demand_generator = DemandGenerator(self.simulation_steps, params, self.logger)
         if demand_pattern:
@@ -518,8 +519,38 @@ class Network:
                 self._engine.set_widths(code, self._widths[which])
             for nidx, tf in self._tf_host.items():
                 self._engine.set_turning_fractions(nidx, tf)
-            self._dirty_demand = {n for n in self.nodes.values() if n._demand is not None}
+            # The model description carried the demand arrays as they were when the engine was created, so nothing is
+            # dirty now: later host-side writes to ``node.demand`` mark their node (DemandArray.on_write), per-replica
+            # uploads through ``set_demand_matrix`` / ``draw_demand`` below clear the mark.
+            self._dirty_demand = set()
         return self._engine
+
+    def set_demand_matrix(self, node_id, values):
+        """Per-replica demand of one origin, ``values [n_replicas, n]`` in one upload (the reference has one array per run)."""
+        node = self.nodes[node_id]
+        self._flush().set_demand_matrix(node.index, values)
+        self._dirty_demand.discard(node)
+        self._invalidate()
+
+    def draw_demand(self, node_id, seed, pattern, base, peak, spike_start, spike_len, spike_height):
+        """Per-replica demand of one origin drawn on the device (``pedn_draw_demand``)."""
+        node = self.nodes[node_id]
+        self._flush().draw_demand(node.index, seed, pattern, base, peak, spike_start, spike_len, spike_height)
+        self._dirty_demand.discard(node)
+        self._invalidate()
+
+    def _invalidate(self):
+        """Cached history columns are keyed by (field, link, replica, step, epoch): anything that can change what a step
+        produces -- reset, new demand, new parameters -- starts a new epoch."""
+        self._epoch += 1
+        self._col_cache.clear()
+
+    def reset(self):
+        """Back to t = 0 in place (the reference rebuilds the Network instead, rl/pz_pednet_env.py:163-168): histories cleared
+        on the device, ``current_step`` 0, no cached column survives."""
+        self._flush().reset()
+        self.current_step = 0
+        self._invalidate()
 
     def _flush(self):
         eng = self.engine()
@@ -527,6 +558,7 @@ class Network:
             for node in self._dirty_demand:
                 eng.set_demand(node.index, np.asarray(node._demand, dtype=np.float64), None)
             self._dirty_demand = set()
+            self._invalidate()
         return eng
 
     def _mark_demand_dirty(self, node):
@@ -537,7 +569,7 @@ class Network:
 
     def _read_column(self, fid, link_index):
         eng = self._flush()
-        key = (fid, link_index, self._replica_index(), self.current_step)
+        key = (fid, link_index, self._replica_index(), self.current_step, self._epoch)
         col = self._col_cache.get(key)
         if col is None:
             if len(self._col_cache) > 4096:
@@ -548,7 +580,7 @@ class Network:
         return col
 
     def _read_element(self, fid, link_index, t):
-        key = (fid, link_index, self._replica_index(), self.current_step)
+        key = (fid, link_index, self._replica_index(), self.current_step, self._epoch)
         col = self._col_cache.get(key)
         if col is not None:
             return col[t]

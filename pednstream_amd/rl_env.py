@@ -221,11 +221,10 @@ class VecPedNetEnv:
         eng = net.engine()
         if options and options.get("randomize", False):
             self.randomize(seed, mode=options.get("mode", "reference"))
-        eng.reset()
+        net.reset()
         net._init_dynamic_host_state()
         for which, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3)):
             eng.set_widths(code, net._widths[which])
-        net.current_step = 0
         self.sim_step = 1
         obs, _ = eng.rl_observe(self.sim_step, accumulate=False)
         return obs, {}
@@ -354,15 +353,11 @@ class PedNetParallelEnv:
                 raise ValueError(f"Unknown agent: {a}")
         row = None
         if len(actions) > 0:
-            # agents without an action keep their current widths (apply_all_actions only touches the given agents)
-            row = np.empty((1, self._vec.n_actions))
+            # agents without an action are left alone (apply_all_actions only touches the given agents): NaN = skip the slot
+            row = np.full((1, self._vec.n_actions), np.nan)
             for aid, sl in self._vec.action_slices.items():
                 if aid in actions:
                     row[0, sl] = np.asarray(actions[aid], dtype=np.float64).reshape(-1)
-                elif self.agent_manager.get_agent_type(aid) == "sep":
-                    row[0, sl] = self.agent_manager.get_separator_links(aid)[0].separator_width
-                else:
-                    row[0, sl] = [l.back_gate_width for l in self.agent_manager.get_gater_outgoing_links(aid)]
         obs, rew, term, trunc, _ = self._vec.step(row)
         rewards = {a: float(rew[0, i]) for i, a in enumerate(self.possible_agents)}
         for a, r in rewards.items():

@@ -217,19 +217,19 @@ class ScenarioBatch:
         for (nid, r), arr in self.demand.items():
             by_node.setdefault(nid, {})[r] = arr
         R, T1 = net.n_replicas, net.simulation_steps + 1
-        for nid, rows in by_node.items():
-            if len(rows) == R and R > 1:        # every replica has its own array: one upload for the node
-                mat = np.zeros((R, T1))
-                for r, arr in rows.items():
-                    n = min(len(arr), T1)
-                    mat[r, :n] = arr[:n]
+        for nid, rows in by_node.items():                   # one upload per origin, whatever subset of replicas it covers
+            reps = sorted(rows)
+            mat = np.zeros((len(reps), T1))
+            for k, r in enumerate(reps):
+                n = min(len(rows[r]), T1)
+                mat[k, :n] = rows[r][:n]
+            if len(reps) == R:
                 eng.set_demand_matrix(net.nodes[nid].index, mat)
             else:
-                for r, arr in rows.items():
-                    eng.set_demand(net.nodes[nid].index, arr, replica=r)
+                eng.set_demand_rows(net.nodes[nid].index, reps, mat)
+            net._dirty_demand.discard(net.nodes[nid])
         self.link_params_dirty = self.od_dirty = False
         self.demand = {}
+        net._invalidate()
         if reset:
-            eng.reset()
-            net.current_step = 0
-            net._col_cache.clear()
+            net.reset()

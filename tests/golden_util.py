@@ -64,6 +64,8 @@ def build_network(g: Golden, **kw):
             net.update_turning_fractions_per_node(g.info["tf_nodes"], np.array(g.info["tf_values"]))
     for nid, arr in g.demand().items():
         net.nodes[nid].demand = arr
+    for lid, (attr, w) in g.info.get("rl", {}).get("init_widths", {}).items():   # widths set before the first env step
+        setattr(net.links[tuple(int(x) for x in lid.split("_"))], attr, w)
     return net
 
 

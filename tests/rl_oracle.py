@@ -23,9 +23,9 @@ class RlOracle:
         self.max_delta_sep = self.max_delta_gate = 0.25 * ut
         self.min_sep = 1.5
         L = model["n_links"]
-        self.front = np.array(model["front_gate0"], dtype=np.float64)
-        self.back = np.array(model["back_gate0"], dtype=np.float64)
-        self.sep = np.array(model["sep_width0"], dtype=np.float64)
+        self.front = np.array([l.front_gate_width for l in self.links], dtype=np.float64)
+        self.back = np.array([l.back_gate_width for l in self.links], dtype=np.float64)
+        self.sep = np.array([l.separator_width if l.is_separator else s0 for l, s0 in zip(self.links, model["sep_width0"])], dtype=np.float64)
         self.sepnp = np.zeros(L)
         self.t = 1
         assert L == len(self.links)
@@ -43,6 +43,8 @@ class RlOracle:
             if ty == "sep":
                 f = links[0]
                 a = float(np.float32(row[k])); k += 1
+                if a != a:          # NaN: the agent is not in the action dict (apply_all_actions only touches the given agents)
+                    continue
                 cur = self.sep[f.index]
                 if abs(a - cur) > self.max_delta_sep:
                     a = cur + np.clip(a - cur, -self.max_delta_sep, self.max_delta_sep)
@@ -54,6 +56,8 @@ class RlOracle:
             else:
                 for l in links:
                     a = float(np.float32(row[k])); k += 1
+                    if a != a:
+                        continue
                     cur = self.back[l.index]
                     if abs(a - cur) > self.max_delta_gate:
                         a = cur + np.clip(a - cur, -self.max_delta_gate, self.max_delta_gate)

@@ -117,7 +117,6 @@ def test_config2_nine_intersections_256_replicas_vs_oracle_and_goldens():
     for r in range(R):
         for nid, k in origins.items():
             e.set_demand(net.nodes[nid].index, replica_demand(500, 3 * r + k, peak=50.0 if nid == 2 else 25.0), replica=r)
-    net._dirty_demand = set()
     net.run(1, steps)
     blocks = {name: e.read_block(LINK_FIELDS[name][0], 0, steps) for name in ALL_FIELDS}    # [t, L, R]
     for r in range(4):
@@ -266,6 +265,18 @@ def test_c_abi_argument_errors_and_reset():
                                 zi.ctypes.data_as(I), zf.ctypes.data_as(F)) < 0 and b"pattern" in lib.pedn_last_error(e._h)
     before = e.get_demand(origin.index, 1)
     assert np.array_equal(before[:len(origin.demand)], np.asarray(origin.demand, dtype=float))     # nothing was overwritten
+    # pedn_set_demand_rows: a subset of replicas in one upload; the others keep what they had; the Network wrapper does not
+    # re-broadcast the base demand afterwards (the node is no longer marked dirty)
+    rows = np.arange(2 * 7, dtype=float).reshape(2, 7) + 1
+    e.set_demand_rows(origin.index, [2, 0], rows)
+    assert np.array_equal(e.get_demand(origin.index, 2)[:9], np.r_[rows[0], 0, 0]) and np.array_equal(e.get_demand(origin.index, 0)[:9], np.r_[rows[1], 0, 0])
+    assert np.array_equal(e.get_demand(origin.index, 1), before)
+    rep = np.array([5], np.int32)
+    assert lib.pedn_set_demand_rows(e._h, origin.index, rep.ctypes.data_as(I), 1, buf.ctypes.data_as(F), 4) < 0 and b"replica" in lib.pedn_last_error(e._h)
+    full = np.stack([before[:e.T + 1]] * 3)
+    net.set_demand_matrix(origin.node_id, full)
+    net.synchronize()
+    assert np.array_equal(e.get_demand(origin.index, 2), before)
     net.run(1, 50)
     a = e.read_block(2, 0, 50)
     e.reset()

@@ -100,6 +100,49 @@ def test_single_env_facade_and_reset(tmp_path):
     env.close()
 
 
+def test_history_reads_after_reset_are_not_served_from_the_previous_episode():
+    """Two episodes with different actions ending at the same step: the cached column read (link.density[...]) must equal a
+    fresh read_block in both (the cache key carries an epoch that every reset / demand / parameter upload bumps)."""
+    g = Golden("rl_nine_opt3")
+    net = build_network(g, n_replicas=2, rng_seed=g.seed)
+    env = VecPedNetEnv("nine_intersections", n_envs=2, obs_mode="option3", network=net)
+    e = net.engine()
+    first = g.info["rl"]["agents"][0]
+    lk = net.links[tuple(int(x) for x in first["links"][0].split("_"))]
+    seen = []
+    for episode, width in enumerate((0.2, 3.8)):
+        env.reset()
+        for k in range(120):
+            env.step(np.full((2, env.n_actions), width))
+        col = np.asarray(lk.density)[:121].copy()                      # column read through the cache
+        fresh = e.read_block(LINK_FIELDS["density"][0], 0, 121, lk.index, lk.index + 1, 0, 1).reshape(-1)
+        assert np.array_equal(col, fresh), episode
+        assert lk.inflow[100] == e.read_element(LINK_FIELDS["inflow"][0], lk.index, 0, 100)     # element read agrees too
+        seen.append(col)
+    assert not np.array_equal(seen[0], seen[1])                        # the two episodes really differ
+    env.close()
+
+
+@pytest.mark.parametrize("case", ["rl_nine_partial", "rl_corridor_partial"])
+def test_partial_action_dicts_leave_the_other_agents_alone(case):
+    """PettingZoo facade with action dicts that miss agents (NaN rows of the golden): apply_all_actions only touches the agents
+    it is given (rl/builders.py:343-352) -- a missing separator agent keeps a width outside the clip band and its float32
+    density division."""
+    g = Golden(case)
+    rl = g.info["rl"]
+    env = PedNetParallelEnv(g.info["scenario"], obs_mode=rl["obs_mode"], seed=g.seed,
+                            network=build_network(g, n_replicas=1, replica_offset=g.replica, rng_seed=g.seed))
+    acts, ref_obs, ref_rew = g.state("rl_actions"), g.state("rl_obs"), g.state("rl_rewards")
+    assert np.isnan(acts).any() and not np.isnan(acts).all()
+    for k in range(rl["env_steps"]):
+        actions = {a: acts[k, sl] for a, sl in env._vec.action_slices.items() if not np.isnan(acts[k, sl]).any()}
+        obs, rew, term, trunc, info = env.step(actions)
+        flat = np.concatenate([obs[a] for a in env.possible_agents])
+        assert np.array_equal(flat, ref_obs[k]), k
+        assert np.array_equal(np.float32([rew[a] for a in env.possible_agents]), ref_rew[k]), k
+    env.close()
+
+
 def test_reference_index_errors_are_reported():
     g = Golden("rl_nine_opt4")
     with pytest.raises(IndexError):

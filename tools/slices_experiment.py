@@ -27,7 +27,6 @@ def build(network, n, offset):
     e = net.engine()
     for nid in net.origin_nodes:
         e.set_demand_matrix(net.nodes[nid].index, np.stack([replica_demand(net.simulation_steps, offset + r) for r in range(n)]))
-    net._dirty_demand = set()
     e.synchronize()
     return net, e
 

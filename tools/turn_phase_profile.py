@@ -26,7 +26,6 @@ def main():
     e = net.engine()
     for nid in net.origin_nodes:
         e.set_demand_matrix(net.nodes[nid].index, np.stack([replica_demand(net.simulation_steps, r) for r in range(R)]))
-    net._dirty_demand = set()
     e.run(1, 150)
     e.synchronize()
     lib.pedn_debug_tphases(None, 1)
