@@ -76,7 +76,35 @@ def build_model_desc(model: dict):
     return desc, keep
 
 
+def _bind_hip_runtime():
+    """One HIP runtime per process, whatever the import order.  PyTorch-ROCm ships its own ``libamdhip64.so`` (soname
+    ``libamdhip64.so.7``, found through torch's RPATH by FILE name); the engine library asks for the soname.  Engine first
+    used to mean: the system runtime is loaded for the engine, torch then loads its private copy next to it, and the second
+    runtime sees no GPU.  So, when torch is installed, its copy is opened here first with RTLD_GLOBAL -- the engine's
+    ``DT_NEEDED libamdhip64.so.7`` then resolves to that already loaded object, and a later ``import torch`` finds its file
+    loaded too.  torch is NOT imported.  ``PEDN_HIP_RUNTIME=system`` keeps the system runtime (torch must then not be used in
+    this process with the GPU)."""
+    if os.environ.get("PEDN_HIP_RUNTIME", "auto") == "system":
+        return None
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+_hip_runtime = None
+
+
 def _load():
+    global _hip_runtime
     if not os.path.exists(LIB_PATH):
         # build on demand when the toolchain is there (same recipe as __graft_entry__.build()); never a CPU fallback
         import shutil
@@ -88,6 +116,7 @@ def _load():
         raise RuntimeError(f"HIP engine library not built: {LIB_PATH} is missing. Run `python -c 'import "
                            f"__graft_entry__ as g; g.build()'` or `make -C pednstream_amd/csrc` (needs hipcc). "
                            f"There is no CPU fallback for the product path.")
+    _hip_runtime = _bind_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     P = C.c_void_p
     sig = {

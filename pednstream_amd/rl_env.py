@@ -248,9 +248,7 @@ class VecPedNetEnv:
         step, so clone what must be kept.  The call waits for the caller's current torch stream before launching and for the
         engine's stream before returning, so plain sequential use is safe.
 
-        torch ships its own copy of the HIP runtime: ``import torch`` BEFORE the first engine of the process is created (the
-        engine library then binds to the copy torch loaded; the other way round the process ends up with two runtimes and torch
-        reports "No HIP GPUs are available")."""
+        torch and the engine share one HIP runtime whichever is imported first (``engine._bind_hip_runtime``)."""
         import torch
 
         if self.sim_step + self.action_gap - 1 > self.simulation_steps:

@@ -151,45 +151,48 @@ def test_reference_index_errors_are_reported():
         VecPedNetEnv("nine_intersections", n_envs=1, obs_mode="option9", network=build_network(g))
 
 
-STEP_DEVICE = r"""
-import torch                                  # before the engine library: one HIP runtime in the process (rl_env.step_device)
-import numpy as np, sys
-sys.path.insert(0, "tests")
-from golden_util import Golden, build_network
-from pednstream_amd.rl_env import VecPedNetEnv
-g = Golden("rl_i45_opt3")
-B, steps = 64, 25
-envs = [VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", network=build_network(g, n_replicas=B, rng_seed=3)) for _ in range(2)]
-rng = np.random.default_rng(4)
-for e in envs:
-    e.reset()
-for k in range(steps):
-    acts = rng.uniform(0, 4, size=(B, envs[0].n_actions))
-    obs_h, rew_h, term_h, _, _ = envs[0].step(acts)
-    obs_d, rew_d, term_d = envs[1].step_device(torch.as_tensor(acts, device="cuda"))
-    assert obs_d.is_cuda and obs_d.dtype == torch.float32 and tuple(obs_d.shape) == obs_h.shape
-    assert np.array_equal(obs_d.cpu().numpy(), obs_h) and np.array_equal(rew_d.cpu().numpy(), rew_h) and term_d == term_h
-assert obs_d.data_ptr() == envs[1].network.engine().rl_device_ptr(1)       # a view, not a copy
-try:
-    envs[1].step_device(torch.zeros((B, envs[1].n_actions), device="cuda", dtype=torch.float32))
-    raise SystemExit("float32 actions were accepted")
-except ValueError:
-    pass
-print("ok")
-"""
+def _step_device_check():
+    """step_device (torch CUDA actions in, torch views of the engine's observation / reward buffers out) == step."""
+    import torch
+
+    assert torch.cuda.is_available(), "torch sees no GPU: two HIP runtimes in the process?"
+    g = Golden("rl_i45_opt3")
+    B, steps = 64, 25
+    envs = [VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", network=build_network(g, n_replicas=B, rng_seed=3)) for _ in range(2)]
+    rng = np.random.default_rng(4)
+    for e in envs:
+        e.reset()
+    for k in range(steps):
+        acts = rng.uniform(0, 4, size=(B, envs[0].n_actions))
+        obs_h, rew_h, term_h, _, _ = envs[0].step(acts)
+        obs_d, rew_d, term_d = envs[1].step_device(torch.as_tensor(acts, device="cuda"))
+        assert obs_d.is_cuda and obs_d.dtype == torch.float32 and tuple(obs_d.shape) == obs_h.shape
+        assert np.array_equal(obs_d.cpu().numpy(), obs_h) and np.array_equal(rew_d.cpu().numpy(), rew_h) and term_d == term_h
+    assert obs_d.data_ptr() == envs[1].network.engine().rl_device_ptr(1)       # a view, not a copy
+    with pytest.raises(ValueError):
+        envs[1].step_device(torch.zeros((B, envs[1].n_actions), device="cuda", dtype=torch.float32))
+    for e in envs:
+        e.close()
 
 
 def test_step_device_aliases_engine_buffers_and_matches_host_step():
-    """step_device (torch CUDA actions in, torch views of the engine's observation / reward buffers out) == step.  Runs in its
-    own process because torch has to be imported before the engine library is loaded."""
+    """In this process the engine library was loaded long before torch is imported (the earlier tests created engines):
+    engine first, torch second.  Both share the one HIP runtime engine._bind_hip_runtime put in place."""
+    pytest.importorskip("torch")
+    _step_device_check()
+
+
+def test_step_device_with_torch_imported_first():
+    """The other import order, in a process of its own."""
+    import importlib.util
     import os
     import subprocess
     import sys
 
-    import importlib.util
-
-    if importlib.util.find_spec("torch") is None:       # (not imported here: the engine library is already loaded in this process)
+    if importlib.util.find_spec("torch") is None:
         pytest.skip("torch is not installed")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", STEP_DEVICE], capture_output=True, text=True, cwd=root, timeout=900)
+    code = ("import torch, sys; torch.zeros(1, device='cuda'); sys.path.insert(0, 'tests'); import test_gpu_rl as t; "
+            "t._step_device_check(); print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
