@@ -12,8 +12,16 @@ and the max-over-ranks reduction of the wall time.
 
 value = links x replicas(all ranks) x K / wall-seconds (max over ranks) of the timed region; inputs are resident in
 HBM before the region starts.  The line also carries
-  roofline     dominant kernel (node_kernel): algorithmic bytes per launch / HIP-event duration vs 8 TB/s
-  cpu_baseline the C restatement under oracle/ timed on this host's cores on a bounded sample of the same workload
+  roofline     dominant kernel (node_kernel): `achieved` / `frac` = ALGORITHMIC bytes per launch / dispatch duration vs 8 TB/s
+               (the contract figure), next to `frac_counter` (bytes the PMC counters saw / the same duration), the whole step
+               (`whole_step_frac`, 212 B per link-update) and `traffic_bytes_per_link_update`
+  cpu_baseline the C restatement under oracle/ timed on this host's cores (1 thread and all cores, CPU model stated) on a
+               bounded sample of the same workload + the derived reference-Python equivalent (profiles/cpu_calibration.json)
+  extra        BASELINE config #3 (delft x 1024) measured in the same run (N = 1 only; --no-extra skips it)
+
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts its N ranks itself (torch.distributed.run as a
+child process, before anything touches the GPU) and exits with the child's code; a WORLD_SIZE that disagrees with --gpus
+is an error.
 """
 import argparse
 import json
@@ -41,8 +49,19 @@ def replica_demand(T, key, base=5.0, peak=10.0):
     return np.random.default_rng(1000 + key).poisson(lam).astype(np.float64)
 
 
-def cpu_baseline(model, net, origin_nodes, threads, seconds_target=12.0):
-    """Oracle (C restatement) on the host cores: `threads` replicas in parallel, full episodes, until ~seconds_target."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _oracle_rate(model, net, origin_nodes, threads, seconds_target, key0=0):
+    """Oracle (C restatement) on `threads` host threads, one replica per thread, full episodes, for ~seconds_target."""
     import oracle_driver as od
 
     T = int(model["T"])
@@ -51,7 +70,7 @@ def cpu_baseline(model, net, origin_nodes, threads, seconds_target=12.0):
     rounds = 0
     while True:
         for i, o in enumerate(oracles):
-            key = rounds * threads + i
+            key = key0 + rounds * threads + i
             o.reset(seed=0, replica=key)
             for nid in origin_nodes:
                 o.set_demand(net.nodes[nid].index, replica_demand(T, key))
@@ -63,25 +82,55 @@ def cpu_baseline(model, net, origin_nodes, threads, seconds_target=12.0):
             break
     for o in oracles:
         o.close()
-    lu = done * (T - 1) * int(model["n_links"])
-    return {"value": lu / el, "unit": "link-updates/s", "cores": threads, "kind": "port",
-            "sample": f"{done} replicas x {T - 1} steps of melbourne on {threads} host threads (oracle/pedn_oracle.c, {el:.1f} s)"}
+    return done * (T - 1) * int(model["n_links"]) / el, done, el
+
+
+def cpu_baseline(model, net, origin_nodes, network, seconds_target=7.0):
+    """the C restatement on this host, 1 thread and all cores, with the CPU named; and the
+    reference-Python equivalent derived through the ratio tools/calibrate_cpu.py measured where the reference lives."""
+    cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = cores
+    T = int(model["T"])
+    one, n1, s1 = _oracle_rate(model, net, origin_nodes, 1, seconds_target)
+    alln, na, sa = _oracle_rate(model, net, origin_nodes, usable, seconds_target, key0=10000)
+    out = {"value": alln, "unit": "link-updates/s", "cores": usable, "kind": "port",
+           "sample": f"{na} replicas x {T - 1} steps of {network} on {usable} host threads ({sa:.1f} s) and {n1} replicas on 1 thread "
+                     f"({s1:.1f} s); oracle/pedn_oracle.c, one replica per thread, same per-replica demand and RNG keys as the GPU run",
+           "one_thread": one, "all_cores": alln, "cores_total": cores, "cores_usable": usable, "cpu_model": cpu_model_name()}
+    cal = os.path.join(ROOT, "profiles", "cpu_calibration.json")
+    if os.path.exists(cal):
+        with open(cal) as f:
+            c = json.load(f)
+        k = c.get("networks", {}).get(network)
+        if k:
+            ratio = k["port_over_reference_1core"]
+            out["reference_python_equiv"] = {
+                "label": "derived, not measured here: port rate on this host / (port / reference ratio measured in the build container)",
+                "one_core": one / ratio, "all_cores": alln / ratio, "port_over_reference_1core": ratio,
+                "calibration": "profiles/cpu_calibration.json (tools/calibrate_cpu.py)", "calibration_host": c.get("host", {})}
+    return out
 
 
 def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc.json, written by
+    """Memory-side bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN[_network]_pmc.json, written by
     tools/summarize_profiles.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  bench.py cannot
-    collect PMC counters on itself; the number is only reported for the workload it was measured on."""
+    collect PMC counters on itself: the number rides along, labelled with its file, only for the workload it was measured on."""
     import glob
-    if network != "melbourne" or replicas != 1024:
+    if replicas != 1024:
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))
+    suffix = "" if network == "melbourne" else f"_{network}"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{suffix}_pmc.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:
         d = json.load(f)
-    k = d.get("kernels", {}).get(kernel)
-    return (k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
+    for name, k in d.get("kernels", {}).items():
+        if name.startswith(kernel):
+            return k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
 
 
 def bench_rl(args):
@@ -125,58 +174,36 @@ def bench_rl(args):
     env.close()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--network", default="melbourne")
-    ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
-                    "multi-rank path on one GPU)")
-    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
-    ap.add_argument("--rng-mode", default="philox", choices=["philox", "meanfield"], help="diagnostic: meanfield removes the RNG work")
-    ap.add_argument("--rl", action="store_true", help="config #5 instead: batched RL env step, env-steps/s")
-    args = ap.parse_args()
-    if args.rl:
-        return bench_rl(args)
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks as a CHILD process (torch.distributed.run, one
+    rank per GPU, rendezvous on 127.0.0.1) before this process has touched the GPU, and hand its exit code back."""
+    import socket
+    import subprocess
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.share_device:
-        local_rank = 0
-    dist = None
-    if "RANK" in os.environ:          # launched by torch.distributed.run, also for N = 1
-        import torch
-        import torch.distributed as dist
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.backend)
 
+def measure(args, network, dist, rank, local_rank, world):
+    """Warm-up, the timed region, per-kernel durations; returns (fields of the JSON line, net, engine-side context)."""
     from pednstream_amd import NetworkEnvGenerator
-    from pednstream_amd.flatten import flatten_network
-
     from pednstream_amd.ensemble import shard
 
     R = args.replicas                                          # weak scaling: R replicas on every GPU
     offset, count = shard(R * world, world, rank)              # contiguous block of global replica ids
     assert count == R
     gen = NetworkEnvGenerator(os.path.join(ROOT, "data"))
-    net = gen.create_network(args.network, verbose=False, n_replicas=R, replica_offset=offset, rng_seed=0,
+    net = gen.create_network(network, verbose=False, n_replicas=R, replica_offset=offset, rng_seed=0,
                              rng_mode=args.rng_mode, device=local_rank)
     T = net.simulation_steps
     e = net.engine()
     origins = list(net.origin_nodes)
-    for k, nid in enumerate(origins):          # one upload per origin: [R, T] rows keyed by the global replica id
-        e.set_demand_matrix(net.nodes[nid].index, np.stack([replica_demand(T, offset + r) for r in range(R)]))
+    for nid in origins:                        # one upload per origin: [R, T] rows keyed by the global replica id
+        net.set_demand_matrix(nid, np.stack([replica_demand(T, offset + r) for r in range(R)]))
     e.synchronize()
     L = e.n_links
 
@@ -185,7 +212,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
         e.synchronize()
 
     # the simulation clock runs 1..T-1; an episode that reaches T is reset and continues (reset is inside the timed region)
@@ -210,51 +238,127 @@ def main():
     dev_ms = e.timer_end()          # HIP events on the engine's stream
     barrier()
     wall = time.perf_counter() - t0
+    ranks_seen = 1
     if dist is not None:
         import torch
-        w = torch.tensor([wall], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        w = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
+        ones = torch.ones(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)           # every rank that really took part adds one
+        ranks_seen = int(ones.item())
     rc, _ = e.error_flags()
     if rc != 0:
         raise SystemExit(f"model error flags set: {rc}")
 
-    # per-kernel durations (HIP events around each launch, same stream), continuing the same simulation
+    # per-kernel durations (the dispatches' own start/stop timestamps, same stream), continuing the same simulation
     prof = []
     for _ in range(min(40, max(8, args.steps // 8))):
-        if state["t"] >= T:
+        if state["t"] >= T - 1:
             e.reset()
             state["t"] = 1
+            e.step(1)                 # the first step of an episode carries the stand-alone turning-fraction launch
+            state["t"] = 2
         prof.append(e.profile_step(state["t"]))
         state["t"] += 1
-    prof = np.array(prof)
-    tf_ms, node_ms, link_ms = prof.mean(axis=0)
+    tf_ms, node_ms, link_ms = np.array(prof).mean(axis=0)
 
-    if rank == 0:
-        total_lu = L * R * world * args.steps
-        value = total_lu / wall
-        node_bytes = NODE_KERNEL_BYTES * L * R
-        achieved = node_bytes / (node_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic("node_kernel", args.network, R)
-        out = {
-            "metric": "link-updates/sec (links x replicas x steps/sec)", "value": value, "unit": "link-updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32", "data": "synthetic",
-            "config": {"workload": f"{args.network} network ({L} links, {len(net.nodes)} nodes, T={T}) x {R} replicas per GPU, "
-                                   f"full-record mode, per-replica Poisson demand and Philox keys",
-                       "replicas_per_gpu": R, "links": L, "parallelism": f"replica-sharded x{world}, no step-path collective"},
-            "device_ms_per_step": dev_ms / args.steps,
-            "roofline": {"bound": "hbm", "kernel": "node_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": node_bytes, "avg_launch_ms": float(node_ms),
-                         "other_kernels_ms": {"link_kernel": float(link_ms), "turn_prob_kernel": float(tf_ms)},
-                         "whole_step_GBps": BYTES_PER_LINK_UPDATE * L * R / ((node_ms + link_ms + tf_ms) * 1e-3) / 1e9},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            threads = min(os.cpu_count() or 1, 16)
-            out["cpu_baseline"] = cpu_baseline(flatten_network(net), net, origins, threads)
-        print(json.dumps(out), flush=True)
+    total_lu = L * R * world * args.steps
+    node_bytes = NODE_KERNEL_BYTES * L * R
+    step_bytes = BYTES_PER_LINK_UPDATE * L * R
+    step_ms = node_ms + link_ms + tf_ms
+    achieved = node_bytes / (node_ms * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic("node_kernel", network, R)
+    mdl = e.model
+    n_dyn_turns = int(np.diff(mdl["node_turn_ptr"])[np.asarray(mdl["node_dyn"]) > 0].sum())     # +8 B each per replica
+    out = {
+        "metric": "link-updates/sec (links x replicas x steps/sec)", "value": total_lu / wall, "unit": "link-updates/s",
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32", "data": "synthetic",
+        "config": {"workload": f"{network} network ({L} links, {len(net.nodes)} nodes, T={T}) x {R} replicas per GPU, "
+                               f"full-record mode, per-replica Poisson demand and Philox keys",
+                   "replicas_per_gpu": R, "links": L, "parallelism": f"replica-sharded x{world}, no step-path collective"},
+        "device_ms_per_step": dev_ms / args.steps,
+        "roofline": {"bound": "hbm", "kernel": "node_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "frac_counter": None if traffic is None else traffic / (node_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic_bytes_per_link_update": None if traffic is None else traffic / (L * R),
+                     "algorithmic_bytes_per_launch": node_bytes, "algorithmic_bytes_per_link_update": NODE_KERNEL_BYTES,
+                     "avg_launch_ms": float(node_ms),
+                     "other_kernels_ms": {"link_kernel(+turn_frac of t+1)": float(link_ms), "turn_frac_kernel(stand-alone)": float(tf_ms)},
+                     "whole_step_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
+                     "whole_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "whole_step_frac_wall": step_bytes / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
+                     "whole_step_bytes_per_link_update": BYTES_PER_LINK_UPDATE,
+                     "dynamic_turns": n_dyn_turns,
+                     "whole_step_frac_incl_dynamic_turns": (step_bytes + 8 * n_dyn_turns * R) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+    }
+    return out, net, origins
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--network", default="melbourne")
+    ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the delft x 1024 (BASELINE config #3) measurement that rides along at N = 1")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                    "multi-rank path on one GPU)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--rng-mode", default="philox", choices=["philox", "meanfield"], help="diagnostic: meanfield removes the RNG work")
+    ap.add_argument("--rl", action="store_true", help="config #5 instead: batched RL env step, env-steps/s")
+    args = ap.parse_args()
+    if args.rl:
+        return bench_rl(args)
+
+    if "RANK" not in os.environ:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
+        if args.gpus > 1:             # nothing has touched the GPU yet: the ranks run in a child, this process only relays its exit code
+            raise SystemExit(spawn_ranks(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_device:
+        local_rank = 0
+    dist = None
+    if "RANK" in os.environ:          # launched by torch.distributed.run, also for N = 1
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
+
+    from pednstream_amd.flatten import flatten_network
+
+    out, net, origins = measure(args, args.network, dist, rank, local_rank, world)
+    if out["ranks_seen"] != world:
+        raise SystemExit(f"only {out['ranks_seen']} of {world} ranks took part")
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(flatten_network(net), net, origins, args.network)
     net.close()
+    if rank == 0 and world == 1 and not args.no_extra and args.network == "melbourne" and args.replicas == 1024:
+        # BASELINE config #3 (the network BASELINE.json names for the rocprof roofline), same engine, same run
+        ex, net3, origins3 = measure(args, "delft", None, 0, local_rank, 1)
+        if not args.no_cpu_baseline:
+            ex["cpu_baseline"] = cpu_baseline(flatten_network(net3), net3, origins3, "delft", seconds_target=4.0)
+        net3.close()
+        out["extra"] = {"config3_delft_x1024": {k: ex[k] for k in ("value", "unit", "ms_per_step", "device_ms_per_step", "config", "roofline")
+                                                 + (("cpu_baseline",) if "cpu_baseline" in ex else ())}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
