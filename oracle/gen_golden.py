@@ -100,6 +100,38 @@ def direct_case(case, adj, params, origin_nodes, destination_nodes=(), steps=Non
                                        "mutations": muts})
 
 
+def step_digests(arr):
+    """uint64 [T]: blake2b-8 of the bytes of arr[:, t] (all columns, C order) for every time index."""
+    import hashlib
+
+    a = np.ascontiguousarray(arr.T)       # [T, columns]
+    return np.array([int.from_bytes(hashlib.blake2b(a[t].tobytes(), digest_size=8).digest(), "little") for t in range(a.shape[0])], dtype=np.uint64)
+
+
+def digest_case(case, name, seed=0, replica=0, np_seed=20261003, demand_override=None, n_sample=16, sample_seed=0):
+    """FULL-horizon pin of a big network in a small file: for every array and every time index a digest over all links, the
+    complete arrays of `n_sample` links (chosen among the busiest and at random), the turning-fraction digests per step."""
+    net, static, state, extras = rh.run_reference(name, seed=seed, replica=replica, np_seed=np_seed, record_tf=True,
+                                                  demand_override=demand_override)
+    tf = tf_matrix(net, extras)
+    L = state["inflow"].shape[0]
+    busy = np.argsort(-state["cumulative_inflow"][:, -2])[:n_sample // 2]
+    rng = np.random.default_rng(sample_seed)
+    rest = rng.choice(np.setdiff1d(np.arange(L), busy), n_sample - len(busy), replace=False)
+    sample = np.sort(np.concatenate([busy, rest]))
+    dig = {k: step_digests(v) for k, v in state.items()}
+    small = {k: (v[sample] if v.shape[0] == L and not k.startswith("v") else v) for k, v in state.items() if not k.startswith("v")}
+    small.update({k: v for k, v in state.items() if k.startswith("v")})           # virtual links are few: keep them whole
+    payload_state = dict(small)
+    payload_state.update({"digest_" + k: v for k, v in dig.items()})
+    payload_state["sample_links"] = sample.astype(np.int32)
+    payload_state["tf_digest"] = step_digests(tf.T)
+    extras2 = {"draws": extras["draws"], "steps_run": extras["steps_run"]}
+    save(case, static, payload_state, extras2, {"scenario": name, "seed": seed, "replica": replica, "mode": "philox", "np_seed": np_seed,
+                                                "mutations": [], "digest": True,
+                                                "totals": {"cumulative_inflow_last": float(state["cumulative_inflow"][:, extras["steps_run"] - 1].sum())}})
+
+
 def randomized_case(case, name, rand_seed, steps=None, replica=0, np_seed=20261003):
     """one scenario drawn by the reference's own randomisers (generate_random_link_params / _od_flows /
     _demand_params, env_loader.py:183-259,363-424; generate_random_od_nodes is NOT applied -- it changes the topology) and
@@ -408,6 +440,15 @@ CASES.update({   # the remaining scenario directories of the reference's data/ (
                                            init_widths={"2_3": ("separator_width", 0.75)}),
     "rl_butterfly_opt3": lambda: rl_case("rl_butterfly_opt3", "butterfly_scC", obs_mode="option3", env_steps=200, action_seed=7),
     "rl_one_intersection_opt5": lambda: rl_case("rl_one_intersection_opt5", "one_intersection_v0", obs_mode="option5", env_steps=200, action_seed=8),
+})
+CASES.update({   # full-horizon pins of the two headline networks (every step, every link, through per-step digests)
+    "melbourne_full": lambda: digest_case("melbourne_full", "melbourne", seed=2, replica=3),
+    "delft_full": lambda: digest_case("delft_full", "delft", seed=1, replica=5),
+    # melbourne under heavy demand: the release binomials, the diffusion look-backs and the congested branch fire
+    "melbourne_heavy_a": lambda: digest_case("melbourne_heavy_a", "melbourne", seed=2, replica=7,
+                                             demand_override={289: replica_demand(500, 7, base=60.0, peak=120.0)}),
+    "melbourne_heavy_b": lambda: digest_case("melbourne_heavy_b", "melbourne", seed=2, replica=8,
+                                             demand_override={289: replica_demand(500, 8, base=150.0, peak=300.0)}),
 })
 for _r in range(4):
     CASES[f"nine_replica{_r}"] = (lambda r=_r: scenario_case(

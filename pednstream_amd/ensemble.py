@@ -10,6 +10,11 @@ tests) is used only to combine results after stepping:
 
 Message sizes are a few KB to a few hundred KB (2 x L x 8 B moments; R x k x 4 B summaries): latency-bound, so a single
 flat collective per call is used and nothing is bucketed.
+
+Both functions take numpy arrays (host results) or torch tensors.  A tensor stays on its device from end to end: with
+the engine's observation / reward buffers (``VecPedNetEnv.step_device`` returns torch views of ``pedn_rl_device_ptr``) and
+backend "nccl" the gather of config #5 (2048 x 20 float32 = 160 KB per step) is one RCCL all_gather over xGMI with no host
+copy; ``VecPedNetEnv.gather_device`` wraps exactly that.
 """
 import numpy as np
 
@@ -45,8 +50,64 @@ def _device():
     return torch.device("cpu")
 
 
-def ensemble_moments(local_values: np.ndarray):
-    """local_values [R_local, ...] -> (count, mean, variance) over ALL ranks' replicas (population variance)."""
+def _is_tensor(x):
+    import sys
+
+    torch = sys.modules.get("torch")
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _moments_tensor(v):
+    """Device path of ``ensemble_moments``: sums, the all_reduce and the result stay on ``v``'s device."""
+    import torch
+
+    v = v.to(torch.float64)
+    k = v[0].numel()
+    packed = torch.cat([torch.tensor([float(v.shape[0])], dtype=torch.float64, device=v.device), v.sum(dim=0).reshape(-1),
+                        (v * v).sum(dim=0).reshape(-1)])
+    dist = _dist()
+    if dist is not None and dist.get_world_size() > 1:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    n = packed[0]
+    mean = (packed[1:1 + k] / n).reshape(v.shape[1:])
+    var = torch.clamp(packed[1 + k:].reshape(v.shape[1:]) / n - mean * mean, min=0.0)
+    return int(n.item()), mean, var
+
+
+def _gather_tensor(a, total_replicas=None):
+    """Device path of ``gather_replica_summaries``: one all_gather_into_tensor when every rank holds the same number of rows
+    (the benchmark's and the RL configuration's case), a padded all_gather otherwise."""
+    import torch
+
+    a = a.contiguous()
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return a
+    world = dist.get_world_size()
+    counts = torch.zeros(world, dtype=torch.int64, device=a.device)
+    counts[dist.get_rank()] = a.shape[0]
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    counts = counts.tolist()
+    if min(counts) == max(counts):
+        out = torch.empty((world * a.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+        dist.all_gather_into_tensor(out, a)
+    else:
+        mx = max(counts)
+        pad = torch.zeros((mx,) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+        pad[:a.shape[0]] = a
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        out = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    if total_replicas is not None and out.shape[0] != total_replicas:
+        raise RuntimeError(f"gathered {out.shape[0]} replicas, expected {total_replicas}")
+    return out
+
+
+def ensemble_moments(local_values):
+    """local_values [R_local, ...] -> (count, mean, variance) over ALL ranks' replicas (population variance).  numpy in ->
+    numpy out; torch tensor in -> tensors on the same device out (no host copy)."""
+    if _is_tensor(local_values):
+        return _moments_tensor(local_values)
     v = np.asarray(local_values, dtype=np.float64)
     n = np.array([v.shape[0]], dtype=np.float64)
     s1, s2 = v.sum(axis=0), (v * v).sum(axis=0)
@@ -63,9 +124,11 @@ def ensemble_moments(local_values: np.ndarray):
     return int(n[0]), mean, var
 
 
-def gather_replica_summaries(local: np.ndarray, total_replicas: int = None):
+def gather_replica_summaries(local, total_replicas: int = None):
     """local [R_local, k] -> [R_total, k] on every rank, rows ordered by global replica id (ranks own contiguous blocks,
-    possibly of different sizes)."""
+    possibly of different sizes).  numpy in -> numpy out; torch tensor in -> a tensor on the same device out (no host copy)."""
+    if _is_tensor(local):
+        return _gather_tensor(local, total_replicas)
     a = np.ascontiguousarray(local)
     dist = _dist()
     if dist is None or dist.get_world_size() == 1:

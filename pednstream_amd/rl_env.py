@@ -276,6 +276,17 @@ class VecPedNetEnv:
         obs, rew = self._device_views
         return obs, rew, (self.sim_step - 1) >= self.simulation_steps
 
+    def gather_device(self, total_envs=None):
+        """Observations and rewards of ALL ranks' envs after ``step_device``: (obs [n_envs_total, n_obs], rewards
+        [n_envs_total, n_agents]) float32 torch tensors on this rank's GPU, rows ordered by global env id -- the engine's
+        buffers go into the collective as they are (RCCL all_gather with backend "nccl"; no host copy)."""
+        from .ensemble import gather_replica_summaries
+
+        if self._device_views is None:
+            raise RuntimeError("call step_device() first")
+        obs, rew = self._device_views
+        return gather_replica_summaries(obs, total_envs), gather_replica_summaries(rew, total_envs)
+
     def split_obs(self, obs_row):
         return {aid: obs_row[..., sl] for aid, sl in self.obs_slices.items()}
 

@@ -127,3 +127,52 @@ def compare_fields(get_field, g: Golden, n_links, last, f32_exact=True):
             l0 = idx[idx[:, 1] == t0][0][0]
             problems.append(f"{name}: {bad.sum()} mismatches, first at t={t0} link={l0}: {mine[l0, t0]!r} vs {ref[l0, t0]!r}")
     return problems
+
+
+DIGEST_CASES = ["melbourne_full", "melbourne_heavy_a", "melbourne_heavy_b", "delft_full"]
+
+
+def step_digests(arr):
+    """uint64 [T]: blake2b-8 of the bytes of arr[:, t] (all columns) for every time index -- as oracle/gen_golden.py stores them."""
+    import hashlib
+
+    a = np.ascontiguousarray(np.asarray(arr).T)
+    return np.array([int.from_bytes(hashlib.blake2b(a[t].tobytes(), digest_size=8).digest(), "little") for t in range(a.shape[0])],
+                    dtype=np.uint64)
+
+
+def compare_digests(get_field, g: Golden, n_links, tf_hist=None):
+    """Full-horizon goldens (oracle/gen_golden.py: digest_case): every array at every time index through its digest over
+    all links, the complete arrays of the sampled links, the virtual links' flows and the turning-fraction digests."""
+    problems = []
+    last = g.steps
+    sample = g.state("sample_links")
+    for name in ALL_FIELDS:
+        mine = np.asarray(get_field(name))
+        ref_small = g.state(name)[:, :last]
+        got_small = mine[sample, :last]
+        if got_small.dtype != ref_small.dtype:
+            problems.append(f"{name}: dtype {got_small.dtype} != {ref_small.dtype}")
+            continue
+        d = step_digests(mine[:n_links, :last])
+        bad = np.flatnonzero(d != g.state("digest_" + name)[:last])
+        if len(bad):
+            problems.append(f"{name}: digest over all links differs at {len(bad)} time indices, first t={bad[0]}")
+        if not np.array_equal(got_small, ref_small):
+            idx = np.argwhere(got_small != ref_small)
+            t0 = idx[:, 1].min()
+            l0 = idx[idx[:, 1] == t0][0][0]
+            problems.append(f"{name}: sampled link {sample[l0]} differs first at t={t0}: {got_small[l0, t0]!r} vs {ref_small[l0, t0]!r}")
+    for tag, off in (("vin", 0), ("vout", 1)):
+        for name in ("inflow", "outflow", "cumulative_inflow", "cumulative_outflow"):
+            key = f"{tag}_{name}"
+            if "state_" + key in g.z.files:
+                mine = np.asarray(get_field(name))[n_links + off::2, :last]
+                if not np.array_equal(mine, g.state(key)[:, :last]):
+                    problems.append(f"{key}: virtual links differ")
+    if tf_hist is not None:
+        d = step_digests(np.asarray(tf_hist).T)
+        bad = np.flatnonzero(d != g.state("tf_digest"))
+        if len(bad):
+            problems.append(f"turning fractions: digest differs at {len(bad)} steps, first index {bad[0]}")
+    return problems

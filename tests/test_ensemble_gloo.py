@@ -46,6 +46,16 @@ def _worker(rank, world, port, total, q):
     local = _densities(range(off, off + cnt))
     n, mean, var = ensemble.ensemble_moments(local)
     gathered = ensemble.gather_replica_summaries(local, total_replicas=total)
+    # the tensor path (what runs on the GPUs with device tensors): same collectives, nothing leaves the tensor's device
+    import torch
+
+    tn, tmean, tvar = ensemble.ensemble_moments(torch.as_tensor(local))
+    tg = ensemble.gather_replica_summaries(torch.as_tensor(local), total_replicas=total)
+    assert isinstance(tg, torch.Tensor) and tn == n
+    assert np.array_equal(tg.numpy(), gathered) and np.allclose(tmean.numpy(), mean, rtol=1e-13) and np.allclose(tvar.numpy(), var, rtol=1e-9, atol=1e-15)
+    even = torch.as_tensor(local[:2])          # equal row counts on both ranks: the all_gather_into_tensor branch
+    ge = ensemble.gather_replica_summaries(even)
+    assert ge.shape[0] == 2 * world and np.array_equal(ge[2 * rank:2 * rank + 2].numpy(), local[:2])
     q.put((rank, off, cnt, n, mean, var, gathered))
     dist.barrier()
     dist.destroy_process_group()

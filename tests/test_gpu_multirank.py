@@ -1,0 +1,94 @@
+"""N > 1 on the GPU without an 8-GPU node: two ranks share GPU 0 (torch.distributed, gloo rendezvous -- RCCL refuses two
+ranks on one device), each owns half of the envs of config #5's batched RL step; observations and rewards go into the
+collective as device tensors (the engine's own buffers, no host copy) and must equal the single-rank run row for row."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOTAL, STEPS = 64, 12
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _actions(step, n_actions):
+    rng = np.random.default_rng(100 + step)
+    return rng.uniform(0.0, 4.0, size=(TOTAL, n_actions))      # row = GLOBAL env id
+
+
+def _run(offset, count, gather):
+    import torch
+
+    from golden_util import Golden, build_network
+    from pednstream_amd.rl_env import VecPedNetEnv
+
+    g = Golden("rl_i45_opt3")
+    net = build_network(g, n_replicas=count, replica_offset=offset, rng_seed=5)
+    env = VecPedNetEnv("45_intersections", n_envs=count, obs_mode="option3", network=net)
+    env.reset()
+    out = []
+    for k in range(STEPS):
+        a = torch.as_tensor(_actions(k, env.n_actions)[offset:offset + count], device="cuda")
+        obs, rew, _ = env.step_device(a)
+        if gather:
+            obs, rew = env.gather_device(total_envs=TOTAL)
+            assert obs.is_cuda and rew.is_cuda and obs.shape[0] == TOTAL
+        out.append((obs.cpu().numpy().copy(), rew.cpu().numpy().copy()))
+    moments = None
+    if gather:
+        from pednstream_amd import ensemble
+
+        n, mean, var = ensemble.ensemble_moments(env._device_views[0])      # device tensor in, device tensors out
+        assert n == TOTAL and mean.is_cuda
+        moments = (mean.cpu().numpy(), var.cpu().numpy())
+    env.close()
+    return out, moments
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    from pednstream_amd import ensemble
+
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    off, cnt = ensemble.shard(TOTAL, world, rank)
+    out, moments = _run(off, cnt, gather=True)
+    q.put((rank, out, moments))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_gather_device_tensors_and_match_the_single_rank_run():
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=600) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref, _ = _run(0, TOTAL, gather=False)
+    for rank, out, moments in results:
+        for k in range(STEPS):
+            assert np.array_equal(out[k][0], ref[k][0]), (rank, k)
+            assert np.array_equal(out[k][1], ref[k][1]), (rank, k)
+        last = ref[-1][0].astype(np.float64)
+        assert np.allclose(moments[0], last.mean(axis=0), rtol=1e-12, atol=1e-12) and np.allclose(moments[1], last.var(axis=0), rtol=1e-9, atol=1e-9)
+    assert not np.array_equal(ref[-1][0][0], ref[-1][0][40])          # envs really differ

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle_driver as od
-from golden_util import ALL_FIELDS, Golden, apply_mutation, build_network, compare_fields
+from golden_util import ALL_FIELDS, DIGEST_CASES, Golden, apply_mutation, build_network, compare_digests, compare_fields
 from pednstream_amd import engine as eng
 from pednstream_amd.flatten import flatten_network
 from pednstream_amd.network import LINK_FIELDS
@@ -104,6 +104,20 @@ def replica_demand(T, r, base=20.0, peak=25.0):
     t = np.arange(T)
     lam = base + peak * np.exp(-(t - T / 4) ** 2 / (2 * (T / 20) ** 2)) + peak * np.exp(-(t - 3 * T / 4) ** 2 / (2 * (T / 20) ** 2))
     return np.random.default_rng(1000 + r).poisson(lam).astype(np.float64)
+
+
+@pytest.mark.parametrize("case", DIGEST_CASES)
+def test_engine_reproduces_full_horizon_reference_runs(case):
+    """The two headline networks over all 499 steps against the reference itself (per-step digests over all links + complete
+    arrays of 16 links + turning-fraction digests); melbourne also under heavy demand."""
+    g = Golden(case)
+    net, tfh = _run_engine_on_golden(g)
+    e = net._engine
+    rc, flags = e.error_flags()
+    assert rc == 0
+    problems = compare_digests(lambda name: e.read_block(LINK_FIELDS[name][0], 0, g.steps)[:, :, 0].T, g, e.n_links, tfh)
+    assert not problems, "\n".join(problems)
+    net.close()
 
 
 def test_config2_nine_intersections_256_replicas_vs_oracle_and_goldens():

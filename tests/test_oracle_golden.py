@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from golden_util import Golden, compare_fields, run_oracle
+from golden_util import DIGEST_CASES, Golden, compare_digests, compare_fields, run_oracle
 
 CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full", "i45_prefix", "delft_prefix",
          "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky", "nine_replica0", "nine_replica1",
@@ -30,3 +30,15 @@ def test_oracle_reproduces_reference_bit_exact(case):
     ref_tf = g.z["tf_hist"]
     assert tfh.shape == ref_tf.shape
     assert np.array_equal(tfh, ref_tf)
+
+
+@pytest.mark.parametrize("case", DIGEST_CASES)
+def test_oracle_reproduces_full_horizon_reference_runs(case):
+    """melbourne / delft over ALL 499 steps (and melbourne under heavy demand, where the release binomials and the diffusion
+    look-backs fire): every array at every step through per-step digests over all links + complete arrays of 16 links."""
+    g = Golden(case)
+    o, tfh, model, net = run_oracle(g)
+    assert o.flags() == 0 and g.steps == model["T"]
+    problems = compare_digests(o.field, g, model["n_links"], tfh)
+    assert not problems, "\n".join(problems)
+    assert o.field("cumulative_inflow")[:model["n_links"], g.steps - 1].sum() == g.info["totals"]["cumulative_inflow_last"]
