@@ -141,7 +141,8 @@ def bench_rl(args):
     from pednstream_amd.rl_env import VecPedNetEnv
 
     B = args.replicas
-    env = VecPedNetEnv(args.network, n_envs=B, obs_mode="option3", action_gap=1, seed=0, data_dir=os.path.join(ROOT, "data"))
+    env = VecPedNetEnv(args.network, n_envs=B, obs_mode="option3", action_gap=1, seed=0, data_dir=os.path.join(ROOT, "data"),
+                       history=args.history)
     e = env.network.engine()
     T = env.simulation_steps
     K = min(args.steps, T - 1 - args.warmup)
@@ -169,7 +170,10 @@ def bench_rl(args):
            "device_ms_per_step": dev_ms / K, "higher_is_better": True, "data": "synthetic", "dtype": "f64+f32",
            "link_updates_per_s": e.n_links * B * K / wall,
            "config": {"workload": f"{args.network} x {B} envs, obs option3 ({env.n_obs} floats), {env.n_actions} action dims, "
-                                  f"agents {env.possible_agents}, actions resident in HBM (torch), obs/rewards left on device"}}
+                                  f"agents {env.possible_agents}, actions resident in HBM (torch), obs/rewards left on device",
+                      "history": args.history,
+                      "history_bytes": int(sum(e.history_rows(f) * (e.n_all if f < 4 else e.n_links) * ((B + 127) // 128 * 128) * (8 if f < 7 else 4)
+                                               for f in range(13)))}}
     print(json.dumps(out), flush=True)
     env.close()
 
@@ -198,7 +202,7 @@ def measure(args, network, dist, rank, local_rank, world):
     assert count == R
     gen = NetworkEnvGenerator(os.path.join(ROOT, "data"))
     net = gen.create_network(network, verbose=False, n_replicas=R, replica_offset=offset, rng_seed=0,
-                             rng_mode=args.rng_mode, device=local_rank)
+                             rng_mode=args.rng_mode, device=local_rank, history=args.history)
     T = net.simulation_steps
     e = net.engine()
     origins = list(net.origin_nodes)
@@ -277,7 +281,7 @@ def measure(args, network, dist, rank, local_rank, world):
         "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32", "data": "synthetic",
         "config": {"workload": f"{network} network ({L} links, {len(net.nodes)} nodes, T={T}) x {R} replicas per GPU, "
-                               f"full-record mode, per-replica Poisson demand and Philox keys",
+                               f"{'full-record' if args.history == 'full' else 'recent-history'} mode, per-replica Poisson demand and Philox keys",
                    "replicas_per_gpu": R, "links": L, "parallelism": f"replica-sharded x{world}, no step-path collective"},
         "device_ms_per_step": dev_ms / args.steps,
         "roofline": {"bound": "hbm", "kernel": "node_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -312,6 +316,8 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--rng-mode", default="philox", choices=["philox", "meanfield"], help="diagnostic: meanfield removes the RNG work")
     ap.add_argument("--rl", action="store_true", help="config #5 instead: batched RL env step, env-steps/s")
+    ap.add_argument("--history", default="full", choices=["full", "recent"], help="full: the reference's footprint (the headline mode); "
+                    "recent: rings for everything the recurrence does not look far back into (include/pedn.h PEDN_HIST_RECENT)")
     args = ap.parse_args()
     if args.rl:
         return bench_rl(args)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PEDN_ABI_VERSION 1
+#define PEDN_ABI_VERSION 2
 #define PEDN_ALL (-1)
 #define PEDN_MAX_DEGREE 8 /* incident corridor slots per node handled by the node kernel */
 
@@ -56,6 +56,9 @@ extern "C" {
 /* RNG modes (oracle/rng_contract.py) */
 #define PEDN_RNG_PHILOX 0
 #define PEDN_RNG_MEANFIELD 1 /* binomial -> floor(n*p), normal -> 0 */
+
+#define PEDN_HIST_FULL 0
+#define PEDN_HIST_RECENT 1
 
 /* width selectors */
 #define PEDN_W_FRONT 0
@@ -134,6 +137,13 @@ typedef struct pedn_model_desc {
   const int32_t* turn_pair_ptr; /* [n_turns+1] -> (entry, upod) products summed into one turning fraction (:668-686) */
   const int32_t* pair_ent;      /* [n_pair] */
   const int32_t* pair_upod;     /* [n_pair] */
+
+  /* PEDN_HIST_FULL: all 13 arrays keep their T+1 entries like the reference's (80 B per link, time index and replica).
+   * PEDN_HIST_RECENT: only what the recurrence itself looks far back into is kept whole -- inflow and cumulative_inflow
+   * (link.py:199-214,284-288: data-dependent look-back); cumulative_outflow keeps max(tau_shockwave) + 2 entries, travel_time
+   * the moving-average window + 2, everything else the last 4.  Same numbers step for step (the batched RL environment
+   * reads nothing older); pedn_read of an entry that has left its ring fails.  16 B + a few rows instead of 80 B. */
+  int32_t history_mode;
 } pedn_model_desc;
 
 typedef struct pedn_sim pedn_sim;
@@ -176,8 +186,11 @@ int pedn_error_flags(pedn_sim* sim, uint32_t* flags);
 int pedn_read(pedn_sim* sim, int32_t field, int32_t t0, int32_t t1, int32_t link0, int32_t link1, int32_t rep0,
               int32_t rep1, void* out);
 
+/* number of time indices field `field` keeps: T+1, or the size of its ring in PEDN_HIST_RECENT mode (time index t lives in
+ * row t mod that size) */
+int pedn_history_rows(pedn_sim* sim, int32_t field);
 /* zero-copy access for on-device consumers: HBM base pointer of a history field laid out
- * [T+1][columns][replica_stride]; columns/replica_stride may be NULL */
+ * [pedn_history_rows][columns][replica_stride]; columns/replica_stride may be NULL */
 void* pedn_device_ptr(pedn_sim* sim, int32_t field, int64_t* columns, int64_t* replica_stride);
 /* hipStream_t the engine launches on */
 void* pedn_stream(pedn_sim* sim);

@@ -56,6 +56,7 @@ struct pedn_sim {
   long step_epoch = 1;  // counts launched steps; h_tf_set_epoch[node] == step_epoch: fractions imposed since the last step
   std::vector<long> h_tf_set_epoch;
   std::vector<int32_t> dbg_rwords, dbg_gwords, dbg_prow;
+  int rows64[7], rows32[6];  // history rows of every field (T+1, or the size of its ring in recent-history mode)
   int last_t = -1;     // last step launched (pedn_get_turning_fractions: which buffer holds a dynamic node's fractions)
   std::vector<void*> allocs;
   // host <-> device staging: two slots used in turn, each a pinned host buffer + a device buffer + the event recorded behind
@@ -135,12 +136,15 @@ static int stage_commit(pedn_sim* s, pedn_sim::Stage* st) {
 
 static int reset_state(pedn_sim* s) {
   DevView& v = s->v;
-  size_t n_all = (size_t)v.T1 * v.Lall * v.RS, n_l = (size_t)v.T1 * v.L * v.RS;
-  for (int f = 0; f < 4; ++f) HIP_TRY(s, hipMemsetAsync(v.f64[f], 0, n_all * sizeof(double), s->stream));
+  for (int f = 0; f < 4; ++f) HIP_TRY(s, hipMemsetAsync(v.f64[f], 0, (size_t)s->rows64[f] * v.Lall * v.RS * sizeof(double), s->stream));
   HIP_TRY(s, hipMemsetAsync(v.flags, 0, (size_t)v.RS * sizeof(uint32_t), s->stream));
   if (v.L > 0) {
+    int max_rows = 0;  // over the fields init_state_kernel fills (all of them have L columns)
+    for (int f = 4; f < 7; ++f) max_rows = std::max(max_rows, s->rows64[f]);
+    for (int g = 0; g < 6; ++g) max_rows = std::max(max_rows, s->rows32[g]);
+    const size_t n_l = (size_t)max_rows * v.L * v.RS;
     unsigned blocks = (unsigned)((n_l + 255) / 256);
-    hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s->stream, v);
+    hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s->stream, v, max_rows);
     HIP_TRY(s, hipGetLastError());
   }
   return PEDN_OK;
@@ -262,6 +266,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   for (int g = 0; g < m->n_grp; ++g)
     if (m->grp_ent_ptr[g + 1] - m->grp_ent_ptr[g] > PEDN_MAX_DEGREE - 1) return fail(nullptr, PEDN_E_ARG, "softmax group too large");
 
+  if (m->history_mode != PEDN_HIST_FULL && m->history_mode != PEDN_HIST_RECENT) return fail(nullptr, PEDN_E_ARG, "unknown history_mode");
+
   HIP_TRY(nullptr, hipSetDevice(device));
   pedn_sim* s = new pedn_sim();
   s->device = device;
@@ -273,6 +279,27 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   v.RS = (n_replicas + 127) / 128 * 128;  // a link_kernel wave covers 128 replicas (2 per lane), a node_kernel wave 64
   v.W = m->window;
   v.dt = m->dt;
+  {  // history rows (DevView.m64 / m32)
+    const int FULL = 0x7fffffff;
+    auto ring = [&](int need) {  // power-of-two ring of at least `need` rows, or all rows when that is no saving
+      int p = 1;
+      while (p < need) p <<= 1;
+      return p >= v.T1 ? FULL : p - 1;
+    };
+    for (int f = 0; f < 7; ++f) v.m64[f] = FULL;
+    for (int g = 0; g < 6; ++g) v.m32[g] = FULL;
+    v.hist = m->history_mode == PEDN_HIST_RECENT;
+    if (v.hist) {
+      int max_sw = 0;
+      for (int l = 0; l < L; ++l) max_sw = std::max(max_sw, m->link_tau_sw[l]);
+      v.m64[F_CO] = ring(max_sw + 2);     // cumulative_outflow[t' + 1 - tau_shockwave] (link.py:380-390) and [t']
+      v.m64[F_OUT] = v.m64[F_S] = v.m64[F_R] = v.m64[F_GATE] = ring(4);   // [t], [t-1], [t-2] at most
+      v.m32[G_TT] = ring(v.W + 2);        // travel_time[t - W] leaves the moving average (link.py:183-186)
+      v.m32[G_ATT] = v.m32[G_N] = v.m32[G_K] = v.m32[G_V] = v.m32[G_LF] = ring(4);
+    }
+    for (int f = 0; f < 7; ++f) s->rows64[f] = v.m64[f] == FULL ? v.T1 : v.m64[f] + 1;
+    for (int g = 0; g < 6; ++g) s->rows32[g] = v.m32[g] == FULL ? v.T1 : v.m32[g] + 1;
+  }
   v.pf_temp = m->pf_temp; v.pf_alpha = m->pf_alpha; v.pf_beta = m->pf_beta; v.pf_omega = m->pf_omega; v.pf_eps = m->pf_eps;
   v.k0 = (uint32_t)seed; v.k1 = (uint32_t)(seed >> 32);
   v.replica_offset = (uint32_t)replica_offset;
@@ -295,8 +322,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   // ---- memory budget
   {
     size_t RS = v.RS, T1 = v.T1;
-    size_t need = 4 * T1 * v.Lall * RS * 8 + 3 * T1 * (size_t)L * RS * 8 + 6 * T1 * (size_t)L * RS * 4 + (size_t)m->n_demand * T1 * RS * 8 +
-                  (size_t)(m->n_turns + m->n_ent + 3 * L) * RS * 8;
+    size_t need = (size_t)(m->n_demand) * T1 * RS * 8 + (size_t)(3 * m->n_turns + 3 * L) * RS * 8;
+    for (int f = 0; f < 7; ++f) need += (size_t)s->rows64[f] * (f < 4 ? v.Lall : L) * RS * 8;
+    for (int g = 0; g < 6; ++g) need += (size_t)s->rows32[g] * L * RS * 4;
     size_t free_b = 0, total_b = 0;
     hipMemGetInfo(&free_b, &total_b);
     if (need + (256u << 20) > free_b) {
@@ -561,9 +589,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   // ---- dynamic state
   {
     size_t RS = v.RS, T1 = v.T1;
-    for (int f = 0; f < 4; ++f) TRY(dalloc(s, T1 * v.Lall * RS, &v.f64[f]));
-    for (int f = 4; f < 7; ++f) TRY(dalloc(s, T1 * (size_t)L * RS, &v.f64[f]));
-    for (int f = 0; f < 6; ++f) TRY(dalloc(s, T1 * (size_t)L * RS, &v.f32[f]));
+    for (int f = 0; f < 7; ++f) TRY(dalloc(s, (size_t)s->rows64[f] * (f < 4 ? v.Lall : L) * RS, &v.f64[f]));
+    for (int g = 0; g < 6; ++g) TRY(dalloc(s, (size_t)s->rows32[g] * L * RS, &v.f32[g]));
     TRY(dalloc(s, (size_t)L * RS, &v.rsum));
     TRY(dalloc(s, (size_t)L * RS, &v.front));
     TRY(dalloc(s, (size_t)L * RS, &v.back));
@@ -979,6 +1006,13 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
   int cols = field < 4 ? v.Lall : v.L;
   if (t0 < 0 || t1 > v.T1 || t0 >= t1 || c0 < 0 || c1 > cols || c0 >= c1 || r0 < 0 || r1 > v.R || r0 >= r1)
     return fail(s, PEDN_E_ARG, "read range out of bounds");
+  const int rows = field < 7 ? s->rows64[field] : s->rows32[field - 7], mask = field < 7 ? v.m64[field] : v.m32[field - 7];
+  if (rows < v.T1) {  // recent-history mode: only the newest `rows` time indices of this field exist
+    const int newest = std::max(s->last_t, 0);
+    if (t1 - 1 > newest || t0 <= newest - rows)
+      return fail(s, PEDN_E_ARG, "time index outside the field's ring (recent-history mode keeps the last " + std::to_string(rows) +
+                                 " entries of this field; the newest is " + std::to_string(newest) + ")");
+  }
   HIP_TRY(s, hipSetDevice(s->device));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   size_t n = (size_t)(t1 - t0) * (c1 - c0) * (r1 - r0);
@@ -989,10 +1023,10 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
   unsigned blocks = (unsigned)((n + 255) / 256);
   if (field < 7)
     hipLaunchKernelGGL(gather_kernel<double>, dim3(blocks), dim3(256), 0, s->stream, (const double*)v.f64[field], (double*)st->dev, t0,
-                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS);
+                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS, mask);
   else
     hipLaunchKernelGGL(gather_kernel<float>, dim3(blocks), dim3(256), 0, s->stream, (const float*)v.f32[field - 7], (float*)st->dev, t0,
-                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS);
+                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS, mask);
   HIP_TRY(s, hipGetLastError());
   HIP_TRY(s, hipMemcpyAsync(st->pin, st->dev, n * esz, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -1005,6 +1039,11 @@ void* pedn_device_ptr(pedn_sim* s, int32_t field, int64_t* columns, int64_t* rep
   if (columns) *columns = field < 4 ? s->v.Lall : s->v.L;
   if (replica_stride) *replica_stride = s->v.RS;
   return field < 7 ? (void*)s->v.f64[field] : (void*)s->v.f32[field - 7];
+}
+
+int pedn_history_rows(pedn_sim* s, int32_t field) {
+  if (!s || field < 0 || field >= PEDN_N_FIELDS) return fail(s, PEDN_E_ARG, "unknown field");
+  return field < 7 ? s->rows64[field] : s->rows32[field - 7];
 }
 
 void* pedn_stream(pedn_sim* s) { return s ? (void*)s->stream : nullptr; }
@@ -1040,6 +1079,7 @@ int pedn_set_link_params(pedn_sim* s, const double* kc, const double* kj, const 
   for (size_t i = 0; i < (size_t)v.L * v.R; ++i) {
     if (!(kj[i] > kc[i]) || !(kc[i] > 0.0) || !(vf[i] > 0.0)) return fail(s, PEDN_E_ARG, "need 0 < k_critical < k_jam and free_flow_speed > 0");
     if (fft[i] < 0 || tau_sw[i] < 0) return fail(s, PEDN_E_ARG, "negative look-back");
+    if (tau_sw[i] + 2 > s->rows64[F_CO]) return fail(s, PEDN_E_ARG, "shock-wave look-back longer than the cumulative_outflow ring (recent-history mode)");
   }
   int rc;
   const size_t n = (size_t)v.L * v.RS;

@@ -32,6 +32,11 @@ __device__ unsigned long long g_tphase[4096 * 8];  // turn_frac_body: [row][stam
 #define TPH(i, dep)
 #endif
 
+// History row of time index t: all T+1 rows are kept in full-record mode (mask = all ones); in recent-history mode
+// (PEDN_HIST_RECENT) the fields nothing looks far back into are rings of a power-of-two number of rows -- see pedn_create.
+#define R64(F, t) ((t) & v.m64[F])
+#define R32(G, t) ((t) & v.m32[G])
+
 __device__ __forceinline__ size_t at(int t, int col, int cols, int RS, int r) {
   return ((size_t)t * (size_t)cols + (size_t)col) * (size_t)RS + (size_t)r;
 }
@@ -63,8 +68,8 @@ __device__ __forceinline__ int wrap_idx(int i, int T1, uint32_t& fl) {
 
 // Link.get_density (link.py:190-197) / Separator.get_density (:427-428) at history index t
 __device__ __forceinline__ float dens_at(const DevView& v, const LinkP& P, int l, int t, int r) {
-  if (P.sep) return v.f32[G_K][at(t, l, v.L, v.RS, r)];
-  float n = v.f32[G_N][at(t, l, v.L, v.RS, r)] + v.f32[G_N][at(t, P.rev, v.L, v.RS, r)];
+  if (P.sep) return v.f32[G_K][at(R32(G_K, t), l, v.L, v.RS, r)];
+  float n = v.f32[G_N][at(R32(G_N, t), l, v.L, v.RS, r)] + v.f32[G_N][at(R32(G_N, t), P.rev, v.L, v.RS, r)];
   return n / (float)(P.length * P.width);
 }
 
@@ -89,7 +94,7 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
   int idx = tp + 1 - tau;
   if (idx < 0) idx = 0;
   float cf = clip01((kk - (float)P.kc) / (float)(P.kj - P.kc));  // link.py:282
-  double ff = v.f64[F_CI][at(idx, l, v.Lall, RS, r)] - x.co_in;  // the one data-dependent look-back of the common path
+  double ff = v.f64[F_CI][at(R64(F_CI, idx), l, v.Lall, RS, r)] - x.co_in;  // the one data-dependent look-back of the common path
   if (!(ff > 0.0)) ff = 0.0;
   double bnd = (double)(cf * nself) + (double)(1.0f - cf) * ff;  // link.py:284-288
   double smax = x.front_in * P.kc * P.vf * v.dt;                 // link.py:296
@@ -258,17 +263,17 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
       entry(e, link, rev, sep, area32, vf, kc, length);
       const int i = e - E0;
       if (!FUSED) {
-        n_l[i] = v.f32[G_N][at(t - 1, link, v.L, RS, r)];
-        n_r[i] = v.f32[G_N][at(t - 1, rev, v.L, RS, r)];
-        if (SEP) k_l[i] = v.f32[G_K][at(t - 1, link, v.L, RS, r)];
+        n_l[i] = v.f32[G_N][at(R32(G_N, t - 1), link, v.L, RS, r)];
+        n_r[i] = v.f32[G_N][at(R32(G_N, t - 1), rev, v.L, RS, r)];
+        if (SEP) k_l[i] = v.f32[G_K][at(R32(G_K, t - 1), link, v.L, RS, r)];
       } else {
-        n_l[i] = v.f32[G_N][at(t - 2, link, v.L, RS, r)];
-        n_r[i] = v.f32[G_N][at(t - 2, rev, v.L, RS, r)];
-        d_l[i] = v.f64[F_IN][at(t - 1, link, v.Lall, RS, r)] - v.f64[F_OUT][at(t - 1, link, v.Lall, RS, r)];
-        d_r[i] = v.f64[F_IN][at(t - 1, rev, v.Lall, RS, r)] - v.f64[F_OUT][at(t - 1, rev, v.Lall, RS, r)];
+        n_l[i] = v.f32[G_N][at(R32(G_N, t - 2), link, v.L, RS, r)];
+        n_r[i] = v.f32[G_N][at(R32(G_N, t - 2), rev, v.L, RS, r)];
+        d_l[i] = v.f64[F_IN][at(R64(F_IN, t - 1), link, v.Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t - 1), link, v.Lall, RS, r)];
+        d_r[i] = v.f64[F_IN][at(R64(F_IN, t - 1), rev, v.Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t - 1), rev, v.Lall, RS, r)];
         if (SEP) { sw[i] = v.sepw[(size_t)link * RS + r]; snp[i] = v.sepnp[(size_t)link * RS + r]; }
       }
-      c_l[i] = v.f64[F_R][at(t2, link, v.L, RS, r)];
+      c_l[i] = v.f64[F_R][at(R64(F_R, t2), link, v.L, RS, r)];
     }
 #pragma unroll
     for (int e = E0; e < E1; ++e) {
@@ -553,8 +558,8 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     const bool tf_shared = W.dyn == 2 ? v.pod_pr == 0 : (W.dyn == 0 && tfu[turn0] == tfu[turn0]);  // tf_u: NaN = per-replica rows
     if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
       s_i = v.demand[((size_t)W.demand_row * v.T1 + tp) * RS + r];
-      co_prev = rowp(v.f64[F_CO], tp, lin, Lall, RS, r0)[lane];
-      ci_prev = rowp(v.f64[F_CI], tp, lout, Lall, RS, r0)[lane];
+      co_prev = rowp(v.f64[F_CO], R64(F_CO, tp), lin, Lall, RS, r0)[lane];
+      ci_prev = rowp(v.f64[F_CI], R64(F_CI, tp), lout, Lall, RS, r0)[lane];
       if (kind == 1) {
 #pragma unroll
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
@@ -572,17 +577,17 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       // back to back (a load skipped by a branch costs a wait at the join); the few values of an `early` step are unused
       SlotIn x;
       const int t_sw = tp + 1 - Pout.tau_sw > 0 ? tp + 1 - Pout.tau_sw : 0;
-      x.n_in = rowp(v.f32[G_N], tp, lin, L, RS, r0)[lane];
-      x.n_out = rowp(v.f32[G_N], tp, lout, L, RS, r0)[lane];
+      x.n_in = rowp(v.f32[G_N], R32(G_N, tp), lin, L, RS, r0)[lane];
+      x.n_out = rowp(v.f32[G_N], R32(G_N, tp), lout, L, RS, r0)[lane];
       // density[t'] of a plain link is num_pedestrians[t'] / float32(length * width) (link.py:136): recomputed from n_in with the
       // link update's own division instead of being read back; a separator's density depends on its width at that time
-      x.k_in = Pin.sep ? rowp(v.f32[G_K], tp, lin, L, RS, r0)[lane] : 0.0f;
-      x.att_in = rowp(v.f32[G_ATT], tp, lin, L, RS, r0)[lane];
-      x.co_in = rowp(v.f64[F_CO], tp, lin, Lall, RS, r0)[lane];
-      x.s_prev = rowp(v.f64[F_S], tm1, lin, L, RS, r0)[lane];
-      x.co_sw = rowp(v.f64[F_CO], t_sw, lout, Lall, RS, r0)[lane];
-      x.ci_out = rowp(v.f64[F_CI], tp, lout, Lall, RS, r0)[lane];
-      x.r_prev = rowp(v.f64[F_R], tm1, lout, L, RS, r0)[lane];
+      x.k_in = Pin.sep ? rowp(v.f32[G_K], R32(G_K, tp), lin, L, RS, r0)[lane] : 0.0f;
+      x.att_in = rowp(v.f32[G_ATT], R32(G_ATT, tp), lin, L, RS, r0)[lane];
+      x.co_in = rowp(v.f64[F_CO], R64(F_CO, tp), lin, Lall, RS, r0)[lane];
+      x.s_prev = rowp(v.f64[F_S], R64(F_S, tm1), lin, L, RS, r0)[lane];
+      x.co_sw = rowp(v.f64[F_CO], R64(F_CO, t_sw), lout, Lall, RS, r0)[lane];
+      x.ci_out = rowp(v.f64[F_CI], R64(F_CI, tp), lout, Lall, RS, r0)[lane];
+      x.r_prev = rowp(v.f64[F_R], R64(F_R, tm1), lout, L, RS, r0)[lane];
       const double fu = v.front_u[lin], bu = v.back_u[lout];
       x.front_in = fu == fu ? fu : v.front[(size_t)lin * RS + r];
       x.back_out = bu == bu ? bu : v.back[(size_t)lout * RS + r];
@@ -599,11 +604,11 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       PH(2, x.n_in + x.k_in + x.att_in + (float)(x.co_in + x.s_prev + x.co_sw + x.ci_out + x.r_prev + x.front_in + x.back_out));
       s_i = early ? 0.0 : send_flow(v, Pin, lin, tp, r, x, fl);
       PH(3, s_i);
-      rowp(v.f64[F_S], tp, lin, L, RS, r0)[lane] = s_i;  // link.py:268,367
+      rowp(v.f64[F_S], R64(F_S, tp), lin, L, RS, r0)[lane] = s_i;  // link.py:268,367
       if (s_i < 0.0) fl |= PEDN_F_NEG_FLOW;
       r_i = recv_flow(v, Pout, lout, tp, r, x, s_i, fl);
       PH(4, r_i);
-      rowp(v.f64[F_R], tp, lout, L, RS, r0)[lane] = r_i;  // node.py:206
+      rowp(v.f64[F_R], R64(F_R, tp), lout, L, RS, r0)[lane] = r_i;  // node.py:206
     }
     if (s_i < 0.0 || r_i < 0.0) fl |= PEDN_F_NEG_FLOW;
 
@@ -669,10 +674,10 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       if (qo < 0.0 || qi < 0.0) fl |= PEDN_F_NEG_FLOW;
     }
     // Node.update_links (node.py:146-162; link.py:19-25)
-    rowp(v.f64[F_OUT], t, lin, Lall, RS, r0)[lane] = qo;
-    rowp(v.f64[F_CO], t, lin, Lall, RS, r0)[lane] = co_prev + qo;
-    rowp(v.f64[F_IN], t, lout, Lall, RS, r0)[lane] = qi;
-    rowp(v.f64[F_CI], t, lout, Lall, RS, r0)[lane] = ci_prev + qi;
+    rowp(v.f64[F_OUT], R64(F_OUT, t), lin, Lall, RS, r0)[lane] = qo;
+    rowp(v.f64[F_CO], R64(F_CO, t), lin, Lall, RS, r0)[lane] = co_prev + qo;
+    rowp(v.f64[F_IN], R64(F_IN, t), lout, Lall, RS, r0)[lane] = qi;
+    rowp(v.f64[F_CI], R64(F_CI, t), lout, Lall, RS, r0)[lane] = ci_prev + qi;
     if (fl) atomicOr(&v.flags[r], fl);
   }
 #ifdef PEDN_PHASE_PROFILE
@@ -752,12 +757,12 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
   const LinkP& Pb = C.Pb;
   const bool win = t >= v.W;
   // ---- loads
-  const double2 ina = ld2(v.f64[F_IN], at(t, a, Lall, RS, r)), outa = ld2(v.f64[F_OUT], at(t, a, Lall, RS, r));
-  const double2 inb = ld2(v.f64[F_IN], at(t, b, Lall, RS, r)), outb = ld2(v.f64[F_OUT], at(t, b, Lall, RS, r));
-  const float2 pa = ld2(v.f32[G_N], at(t - 1, a, L, RS, r)), pb = ld2(v.f32[G_N], at(t - 1, b, L, RS, r));
+  const double2 ina = ld2(v.f64[F_IN], at(R64(F_IN, t), a, Lall, RS, r)), outa = ld2(v.f64[F_OUT], at(R64(F_OUT, t), a, Lall, RS, r));
+  const double2 inb = ld2(v.f64[F_IN], at(R64(F_IN, t), b, Lall, RS, r)), outb = ld2(v.f64[F_OUT], at(R64(F_OUT, t), b, Lall, RS, r));
+  const float2 pa = ld2(v.f32[G_N], at(R32(G_N, t - 1), a, L, RS, r)), pb = ld2(v.f32[G_N], at(R32(G_N, t - 1), b, L, RS, r));
   const float2 rsa = ld2(v.rsum, (size_t)a * RS + r), rsb = ld2(v.rsum, (size_t)b * RS + r);
-  const float2 oa = win ? ld2(v.f32[G_TT], at(t - v.W, a, L, RS, r)) : make_float2(0.f, 0.f);
-  const float2 ob = win ? ld2(v.f32[G_TT], at(t - v.W, b, L, RS, r)) : make_float2(0.f, 0.f);
+  const float2 oa = win ? ld2(v.f32[G_TT], at(R32(G_TT, t - v.W), a, L, RS, r)) : make_float2(0.f, 0.f);
+  const float2 ob = win ? ld2(v.f32[G_TT], at(R32(G_TT, t - v.W), b, L, RS, r)) : make_float2(0.f, 0.f);
   const double bua = v.back_u[a], bub = v.back_u[b];
   double2 wa = make_double2(Pa.width, Pa.width), wb = make_double2(Pb.width, Pb.width), fa = make_double2(0, 0), fb = make_double2(0, 0);
   if (Pa.sep) { wa = ld2(v.sepw, (size_t)a * RS + r); fa = ld2(v.sepnp, (size_t)a * RS + r); }
@@ -783,25 +788,25 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
     sb[j] = speed_calc(v, Pb, b, t, r + j, kb[j], ka[j], rsbv[j], obv[j]);
   }
   // ---- stores
-  st2(v.f32[G_N], at(t, a, L, RS, r), na[0], na[1]);
-  st2(v.f32[G_N], at(t, b, L, RS, r), nb[0], nb[1]);
-  st2(v.f32[G_K], at(t, a, L, RS, r), ka[0], ka[1]);
-  st2(v.f32[G_K], at(t, b, L, RS, r), kb[0], kb[1]);
-  st2(v.f32[G_V], at(t, a, L, RS, r), sa[0].spd, sa[1].spd);
-  st2(v.f32[G_V], at(t, b, L, RS, r), sb[0].spd, sb[1].spd);
-  st2(v.f32[G_TT], at(t, a, L, RS, r), sa[0].tt, sa[1].tt);
-  st2(v.f32[G_TT], at(t, b, L, RS, r), sb[0].tt, sb[1].tt);
-  st2(v.f32[G_LF], at(t, a, L, RS, r), sa[0].lf, sa[1].lf);
-  st2(v.f32[G_LF], at(t, b, L, RS, r), sb[0].lf, sb[1].lf);
+  st2(v.f32[G_N], at(R32(G_N, t), a, L, RS, r), na[0], na[1]);
+  st2(v.f32[G_N], at(R32(G_N, t), b, L, RS, r), nb[0], nb[1]);
+  st2(v.f32[G_K], at(R32(G_K, t), a, L, RS, r), ka[0], ka[1]);
+  st2(v.f32[G_K], at(R32(G_K, t), b, L, RS, r), kb[0], kb[1]);
+  st2(v.f32[G_V], at(R32(G_V, t), a, L, RS, r), sa[0].spd, sa[1].spd);
+  st2(v.f32[G_V], at(R32(G_V, t), b, L, RS, r), sb[0].spd, sb[1].spd);
+  st2(v.f32[G_TT], at(R32(G_TT, t), a, L, RS, r), sa[0].tt, sa[1].tt);
+  st2(v.f32[G_TT], at(R32(G_TT, t), b, L, RS, r), sb[0].tt, sb[1].tt);
+  st2(v.f32[G_LF], at(R32(G_LF, t), a, L, RS, r), sa[0].lf, sa[1].lf);
+  st2(v.f32[G_LF], at(R32(G_LF, t), b, L, RS, r), sb[0].lf, sb[1].lf);
   if (win) {
-    st2(v.f32[G_ATT], at(t, a, L, RS, r), sa[0].att, sa[1].att);
-    st2(v.f32[G_ATT], at(t, b, L, RS, r), sb[0].att, sb[1].att);
+    st2(v.f32[G_ATT], at(R32(G_ATT, t), a, L, RS, r), sa[0].att, sa[1].att);
+    st2(v.f32[G_ATT], at(R32(G_ATT, t), b, L, RS, r), sb[0].att, sb[1].att);
   }
   st2(v.rsum, (size_t)a * RS + r, sa[0].rs, sa[1].rs);
   st2(v.rsum, (size_t)b * RS + r, sb[0].rs, sb[1].rs);
   // the record is initialised to `width` (link.py:56), so an unchanged gate needs no store
-  if (ga.x != Pa.width || ga.y != Pa.width) st2(v.f64[F_GATE], at(t, a, L, RS, r), ga.x, ga.y);
-  if (gb.x != Pb.width || gb.y != Pb.width) st2(v.f64[F_GATE], at(t, b, L, RS, r), gb.x, gb.y);
+  if (ga.x != Pa.width || ga.y != Pa.width || v.hist) st2(v.f64[F_GATE], at(R64(F_GATE, t), a, L, RS, r), ga.x, ga.y);
+  if (gb.x != Pb.width || gb.y != Pb.width || v.hist) st2(v.f64[F_GATE], at(R64(F_GATE, t), b, L, RS, r), gb.x, gb.y);
 }
 
 // Same update with per-replica link parameters: one replica per lane (the parameters live in vector registers).
@@ -814,25 +819,25 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
   const int a = C.a, b = C.b;
   const LinkP Pa = lane_params<true>(v, C.Pa, a, r), Pb = lane_params<true>(v, C.Pb, b, r);
   const bool win = t >= v.W;
-  const double da = v.f64[F_IN][at(t, a, Lall, RS, r)] - v.f64[F_OUT][at(t, a, Lall, RS, r)];
-  const double db = v.f64[F_IN][at(t, b, Lall, RS, r)] - v.f64[F_OUT][at(t, b, Lall, RS, r)];
-  const float na = (float)((double)v.f32[G_N][at(t - 1, a, L, RS, r)] + da), nb = (float)((double)v.f32[G_N][at(t - 1, b, L, RS, r)] + db);
+  const double da = v.f64[F_IN][at(R64(F_IN, t), a, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), a, Lall, RS, r)];
+  const double db = v.f64[F_IN][at(R64(F_IN, t), b, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), b, Lall, RS, r)];
+  const float na = (float)((double)v.f32[G_N][at(R32(G_N, t - 1), a, L, RS, r)] + da), nb = (float)((double)v.f32[G_N][at(R32(G_N, t - 1), b, L, RS, r)] + db);
   const double wa = Pa.sep ? v.sepw[(size_t)a * RS + r] : Pa.width, wb = Pb.sep ? v.sepw[(size_t)b * RS + r] : Pb.width;
   const float ka = (Pa.sep && v.sepnp[(size_t)a * RS + r] != 0.0) ? (float)((double)na / (Pa.length * wa)) : na / (float)(Pa.length * wa);
   const float kb = (Pb.sep && v.sepnp[(size_t)b * RS + r] != 0.0) ? (float)((double)nb / (Pb.length * wb)) : nb / (float)(Pb.length * wb);
-  const float oa = win ? v.f32[G_TT][at(t - v.W, a, L, RS, r)] : 0.0f, ob = win ? v.f32[G_TT][at(t - v.W, b, L, RS, r)] : 0.0f;
+  const float oa = win ? v.f32[G_TT][at(R32(G_TT, t - v.W), a, L, RS, r)] : 0.0f, ob = win ? v.f32[G_TT][at(R32(G_TT, t - v.W), b, L, RS, r)] : 0.0f;
   const SpeedOut sa = speed_calc(v, Pa, a, t, r, ka, kb, v.rsum[(size_t)a * RS + r], oa);
   const SpeedOut sb = speed_calc(v, Pb, b, t, r, kb, ka, v.rsum[(size_t)b * RS + r], ob);
   const double ga = Pa.sep ? wa : v.back[(size_t)a * RS + r], gb = Pb.sep ? wb : v.back[(size_t)b * RS + r];
-  v.f32[G_N][at(t, a, L, RS, r)] = na; v.f32[G_N][at(t, b, L, RS, r)] = nb;
-  v.f32[G_K][at(t, a, L, RS, r)] = ka; v.f32[G_K][at(t, b, L, RS, r)] = kb;
-  v.f32[G_V][at(t, a, L, RS, r)] = sa.spd; v.f32[G_V][at(t, b, L, RS, r)] = sb.spd;
-  v.f32[G_TT][at(t, a, L, RS, r)] = sa.tt; v.f32[G_TT][at(t, b, L, RS, r)] = sb.tt;
-  v.f32[G_LF][at(t, a, L, RS, r)] = sa.lf; v.f32[G_LF][at(t, b, L, RS, r)] = sb.lf;
-  if (win) { v.f32[G_ATT][at(t, a, L, RS, r)] = sa.att; v.f32[G_ATT][at(t, b, L, RS, r)] = sb.att; }
+  v.f32[G_N][at(R32(G_N, t), a, L, RS, r)] = na; v.f32[G_N][at(R32(G_N, t), b, L, RS, r)] = nb;
+  v.f32[G_K][at(R32(G_K, t), a, L, RS, r)] = ka; v.f32[G_K][at(R32(G_K, t), b, L, RS, r)] = kb;
+  v.f32[G_V][at(R32(G_V, t), a, L, RS, r)] = sa.spd; v.f32[G_V][at(R32(G_V, t), b, L, RS, r)] = sb.spd;
+  v.f32[G_TT][at(R32(G_TT, t), a, L, RS, r)] = sa.tt; v.f32[G_TT][at(R32(G_TT, t), b, L, RS, r)] = sb.tt;
+  v.f32[G_LF][at(R32(G_LF, t), a, L, RS, r)] = sa.lf; v.f32[G_LF][at(R32(G_LF, t), b, L, RS, r)] = sb.lf;
+  if (win) { v.f32[G_ATT][at(R32(G_ATT, t), a, L, RS, r)] = sa.att; v.f32[G_ATT][at(R32(G_ATT, t), b, L, RS, r)] = sb.att; }
   v.rsum[(size_t)a * RS + r] = sa.rs; v.rsum[(size_t)b * RS + r] = sb.rs;
-  if (ga != Pa.width) v.f64[F_GATE][at(t, a, L, RS, r)] = ga;
-  if (gb != Pb.width) v.f64[F_GATE][at(t, b, L, RS, r)] = gb;
+  if (ga != Pa.width || v.hist) v.f64[F_GATE][at(R64(F_GATE, t), a, L, RS, r)] = ga;
+  if (gb != Pb.width || v.hist) v.f64[F_GATE][at(R64(F_GATE, t), b, L, RS, r)] = gb;
 }
 
 __global__ __launch_bounds__(256) void link_kernel(DevView v, int t) { link_body(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
@@ -901,8 +906,8 @@ __device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& 
   if (type == 0) {  // separator agent, builders.py:87-117
     if (wv == 0 && live) {
       const int f = q.agent_links[la], b = q.agent_links[la + 1];
-      float x[4] = {(float)v.f64[F_IN][at(t, f, Lall, RS, r)], (float)v.f64[F_OUT][at(t, f, Lall, RS, r)],
-                    (float)v.f64[F_IN][at(t, b, Lall, RS, r)], (float)v.f64[F_OUT][at(t, b, Lall, RS, r)]};
+      float x[4] = {(float)v.f64[F_IN][at(R64(F_IN, t), f, Lall, RS, r)], (float)v.f64[F_OUT][at(R64(F_OUT, t), f, Lall, RS, r)],
+                    (float)v.f64[F_IN][at(R64(F_IN, t), b, Lall, RS, r)], (float)v.f64[F_OUT][at(R64(F_OUT, t), b, Lall, RS, r)]};
       for (int k = 0; k < 4; ++k) {
         if (q.normalize && (q.obs_mode == 1 || q.obs_mode == 2)) x[k] = x[k] / 20.0f;  // builders.py:183-188
         o[k] = x[k];
@@ -913,19 +918,19 @@ __device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& 
     for (int w = wv; w < n; w += 4) {
       const int l = q.agent_links[la + w];
       const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
-      const double in_ld = v.f64[F_IN][at(t, l, Lall, RS, r)], out_ld = v.f64[F_OUT][at(t, l, Lall, RS, r)];
-      const double in_rd = v.f64[F_IN][at(t, P.rev, Lall, RS, r)], out_rd = v.f64[F_OUT][at(t, P.rev, Lall, RS, r)];
+      const double in_ld = v.f64[F_IN][at(R64(F_IN, t), l, Lall, RS, r)], out_ld = v.f64[F_OUT][at(R64(F_OUT, t), l, Lall, RS, r)];
+      const double in_rd = v.f64[F_IN][at(R64(F_IN, t), P.rev, Lall, RS, r)], out_rd = v.f64[F_OUT][at(R64(F_OUT, t), P.rev, Lall, RS, r)];
       const float in_l = (float)in_ld, out_l = (float)out_ld, in_r = (float)in_rd, out_r = (float)out_rd;
       float tt_l, tt_r, spd, dens;
       if (!FUSED) {
-        tt_l = v.f32[G_TT][at(t, l, L, RS, r)];
-        tt_r = v.f32[G_TT][at(t, P.rev, L, RS, r)];
-        spd = q.obs_mode == 5 ? v.f32[G_V][at(t, l, L, RS, r)] : 0.0f;
+        tt_l = v.f32[G_TT][at(R32(G_TT, t), l, L, RS, r)];
+        tt_r = v.f32[G_TT][at(R32(G_TT, t), P.rev, L, RS, r)];
+        spd = q.obs_mode == 5 ? v.f32[G_V][at(R32(G_V, t), l, L, RS, r)] : 0.0f;
         dens = dens_at(v, P, l, t, r);
       } else {  // link.py:133-136 + update_speeds, as in link_body
         const LinkP Pr = v.pr ? lane_params<true>(v, v.lp[P.rev], P.rev, r) : v.lp[P.rev];
-        const float na = (float)((double)v.f32[G_N][at(t - 1, l, L, RS, r)] + (in_ld - out_ld));
-        const float nb = (float)((double)v.f32[G_N][at(t - 1, P.rev, L, RS, r)] + (in_rd - out_rd));
+        const float na = (float)((double)v.f32[G_N][at(R32(G_N, t - 1), l, L, RS, r)] + (in_ld - out_ld));
+        const float nb = (float)((double)v.f32[G_N][at(R32(G_N, t - 1), P.rev, L, RS, r)] + (in_rd - out_rd));
         const double wa = P.sep ? v.sepw[(size_t)l * RS + r] : P.width, wb = Pr.sep ? v.sepw[(size_t)P.rev * RS + r] : Pr.width;
         const float ka = (P.sep && v.sepnp[(size_t)l * RS + r] != 0.0) ? (float)((double)na / (P.length * wa)) : na / (float)(P.length * wa);
         const float kb = (Pr.sep && v.sepnp[(size_t)P.rev * RS + r] != 0.0) ? (float)((double)nb / (Pr.length * wb)) : nb / (float)(Pr.length * wb);
@@ -1010,36 +1015,40 @@ __global__ __launch_bounds__(256) void link_turn_kernel(DevView v, int t, unsign
 }
 
 // ---- state initialisation / host <-> device helpers ---------------------------------------------------------
-__global__ void init_state_kernel(DevView v) {
-  const int RS = v.RS, L = v.L, T1 = v.T1;
+__global__ void init_state_kernel(DevView v, int max_rows) {
+  const int RS = v.RS, L = v.L;
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)T1 * L * RS;
+  size_t total = (size_t)max_rows * L * RS;
   if (gid >= total) return;
   int r = (int)(gid % RS);
   int l = (int)((gid / RS) % L);
-  int t = (int)(gid / ((size_t)RS * L));
+  int t = (int)(gid / ((size_t)RS * L));  // history row (full-record mode: the time index; recent-history mode: a ring slot)
   const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
-  v.f64[F_S][gid] = -1.0;
-  v.f64[F_R][gid] = -1.0;
-  v.f64[F_GATE][gid] = P.width;  // link.py:56
-  v.f32[G_TT][gid] = t == 0 ? P.tt0 : 0.0f;
-  v.f32[G_ATT][gid] = t < v.W ? P.tt0 : 0.0f;  // link.py:91
-  v.f32[G_N][gid] = 0.0f;
-  v.f32[G_K][gid] = 0.0f;
-  v.f32[G_V][gid] = 0.0f;
-  v.f32[G_LF][gid] = 0.0f;
+  auto has64 = [&](int f) { return t <= v.m64[f]; };  // rows of a field = mask + 1 (a ring), or all of max_rows
+  auto has32 = [&](int g) { return t <= v.m32[g]; };
+  if (has64(F_S)) v.f64[F_S][gid] = -1.0;
+  if (has64(F_R)) v.f64[F_R][gid] = -1.0;
+  if (has64(F_GATE)) v.f64[F_GATE][gid] = P.width;  // link.py:56
+  if (has32(G_TT)) v.f32[G_TT][gid] = t == 0 ? P.tt0 : 0.0f;
+  // link.py:91: avg_travel_time[t] = travel_time[0] for t < W; the link update only writes it from t = W on, so the slots
+  // of a ring (fewer rows than W) all start there
+  if (has32(G_ATT)) v.f32[G_ATT][gid] = (t < v.W || v.hist) ? P.tt0 : 0.0f;
+  if (has32(G_N)) v.f32[G_N][gid] = 0.0f;
+  if (has32(G_K)) v.f32[G_K][gid] = 0.0f;
+  if (has32(G_V)) v.f32[G_V][gid] = 0.0f;
+  if (has32(G_LF)) v.f32[G_LF][gid] = 0.0f;
   if (t == 0) v.rsum[(size_t)l * RS + r] = P.tt0;  // link.py:84
 }
 
 template <typename T>
-__global__ void gather_kernel(const T* src, T* dst, int t0, int nt, int c0, int nc, int r0, int nr, int cols, int RS) {
+__global__ void gather_kernel(const T* src, T* dst, int t0, int nt, int c0, int nc, int r0, int nr, int cols, int RS, int mask) {
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)nt * nc * nr;
   if (gid >= total) return;
   int r = (int)(gid % nr);
   int c = (int)((gid / nr) % nc);
   int t = (int)(gid / ((size_t)nr * nc));
-  dst[gid] = src[((size_t)(t0 + t) * cols + (c0 + c)) * RS + (r0 + r)];
+  dst[gid] = src[((size_t)((t0 + t) & mask) * cols + (c0 + c)) * RS + (r0 + r)];
 }
 
 // dst[(row0 + i) * RS + r] = src[i * src_stride + (per_replica ? r : 0)] for r in [r0, r1)

@@ -82,4 +82,9 @@ struct DevView {
   uint32_t k0, k1, replica_offset;
   int32_t meanfield;
   int32_t dbg;
+  // history rows: time index t lives in row (t & mask).  Full-record mode: every mask is 0x7fffffff (row = t, T+1 rows, the
+  // reference's own footprint).  Recent-history mode (hist = 1): inflow and cumulative_inflow keep all rows (the sending
+  // flow looks back an unbounded, data-dependent number of steps into them), the others are rings of mask + 1 rows.
+  int32_t m64[7], m32[6];
+  int32_t hist;
 };

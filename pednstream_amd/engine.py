@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PEDN_HIP_LIB") or os.path.join(_HERE, "csrc", "libpedn_hip.so")   # env override: A/B builds
 
 PEDN_ALL = -1
-ABI_VERSION = 1
+ABI_VERSION = 2
 ERROR_BITS = {1: "negative sending flow (ValueError, link.py:345-346,365-366)",
               2: "negative flows at a node (Warning, node.py:192-194,218-219,237-238)",
               4: "history index out of range (IndexError)",
@@ -44,6 +44,7 @@ class ModelDesc(C.Structure):
         ("node_up_ptr", _I32P), ("up_slot", _I32P), ("up_od_ptr", _I32P), ("upod_od", _I32P), ("node_grp_ptr", _I32P),
         ("grp_ent_ptr", _I32P), ("grp_allphys", _I32P), ("grp_node", _I32P), ("ent_link", _I32P), ("ent_dist", _F64P),
         ("turn_pair_ptr", _I32P), ("pair_ent", _I32P), ("pair_upod", _I32P),
+        ("history_mode", C.c_int32),
     ]
 
 
@@ -72,7 +73,7 @@ def build_model_desc(model: dict):
             keep.append(arr)
             setattr(desc, name, arr.ctypes.data_as(ctype))
         else:
-            setattr(desc, name, model[name])
+            setattr(desc, name, model.get(name, 0) if name == "history_mode" else model[name])
     return desc, keep
 
 
@@ -142,6 +143,7 @@ def _load():
         "pedn_error_flags": (C.c_int, [P, C.POINTER(C.c_uint32)]),
         "pedn_read": (C.c_int, [P, C.c_int32] + [C.c_int32] * 6 + [C.c_void_p]),
         "pedn_device_ptr": (C.c_void_p, [P, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+        "pedn_history_rows": (C.c_int, [P, C.c_int32]),
         "pedn_stream": (C.c_void_p, [P]),
         "pedn_timer_begin": (C.c_int, [P]),
         "pedn_timer_end": (C.c_int, [P, C.POINTER(C.c_float)]),
@@ -177,7 +179,7 @@ def lib():
 EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand", "pedn_set_demand_matrix", "pedn_set_demand_rows", "pedn_get_demand", "pedn_draw_demand",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
-           "pedn_device_ptr", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_rl_configure",
+           "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_rl_configure",
            "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
            "pedn_set_od_weights_per_replica"]
 
@@ -436,6 +438,10 @@ class Engine:
         self._ck(self._lib.pedn_read(self._h, int(field), int(t0), int(t1), int(link0), int(link1), int(rep0), int(rep1),
                                      out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def history_rows(self, field):
+        """Time indices the field keeps: T + 1, or the size of its ring in recent-history mode."""
+        return self._ck(self._lib.pedn_history_rows(self._h, int(field)))
 
     def read_column(self, field, link, replica=0):
         return self.read_block(field, 0, self.T + 1, link, link + 1, replica, replica + 1).reshape(-1)

@@ -21,7 +21,8 @@ def flatten_network(net) -> dict:
     links = net._link_list
     L, N = len(links), len(nodes)
     T = int(net.simulation_steps)
-    m = {"n_nodes": N, "n_links": L, "n_vlinks": int(net.n_vlinks), "T": T, "dt": float(net.unit_time)}
+    m = {"n_nodes": N, "n_links": L, "n_vlinks": int(net.n_vlinks), "T": T, "dt": float(net.unit_time),
+         "history_mode": {"full": 0, "recent": 1}[getattr(net, "history", "full")]}
 
     # ---- nodes / slots -------------------------------------------------------------------------------------
     slot_ptr, turn_ptr = [0], [0]

@@ -32,6 +32,7 @@ LINK_FIELDS = {
     "density": (10, np.float32), "speed": (11, np.float32), "link_flow": (12, np.float32),
 }
 VIRTUAL_FIELDS = ("inflow", "outflow", "cumulative_inflow", "cumulative_outflow")
+LINK_DTYPES = {fid: dt for fid, dt in LINK_FIELDS.values()}
 
 
 class HistoryArray:
@@ -352,7 +353,13 @@ class Network:
                  destination_nodes: list = [], demand_pattern: List[Callable] = None,
                  od_flows: dict = None, pos: dict = None, log_level: int = logging.INFO, verbose: bool = True,
                  n_replicas: int = 1, replica_offset: int = 0, rng_seed: int = 0, rng_mode: str = "philox",
-                 device: int = 0):
+                 device: int = 0, history: str = "full"):
+        """``history``: "full" keeps every history array whole like the reference (80 B per link, time index and replica);
+        "recent" keeps only what the recurrence looks far back into (include/pedn.h: PEDN_HIST_RECENT) -- same numbers step
+        for step, reads of entries that have left their ring raise IndexError."""
+        if history not in ("full", "recent"):
+            raise ValueError(f"history must be 'full' or 'recent', got {history!r}")
+        self.history = history
         self.verbose = verbose
         self.logger = self.setup_logger(log_level) if verbose else None
         self.adjacency_matrix = adjacency_matrix
@@ -574,7 +581,15 @@ class Network:
         if col is None:
             if len(self._col_cache) > 4096:
                 self._col_cache.clear()
-            col = eng.read_column(fid, link_index, self._replica_index())
+            rows = eng.history_rows(fid)
+            if rows < self.simulation_steps + 1:      # recent-history mode: the entries still in the ring, NaN elsewhere
+                hi = max(self.current_step, 0)
+                lo = max(0, hi - rows + 1)
+                col = np.full(self.simulation_steps + 1, np.nan, dtype=LINK_DTYPES[fid])
+                col[lo:hi + 1] = eng.read_block(fid, lo, hi + 1, link_index, link_index + 1, self._replica_index(),
+                                                self._replica_index() + 1).reshape(-1)
+            else:
+                col = eng.read_column(fid, link_index, self._replica_index())
             col.setflags(write=False)
             self._col_cache[key] = col
         return col
@@ -584,7 +599,12 @@ class Network:
         col = self._col_cache.get(key)
         if col is not None:
             return col[t]
-        return self._flush().read_element(fid, link_index, self._replica_index(), t)
+        try:
+            return self._flush().read_element(fid, link_index, self._replica_index(), t)
+        except RuntimeError as err:
+            if "ring" in str(err):
+                raise IndexError(str(err)) from None
+            raise
 
     def _refresh_widths(self):
         """Pull the widths back after the device changed them (batched RL actions)."""

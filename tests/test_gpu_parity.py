@@ -407,3 +407,40 @@ def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, monkeypatch):
             ran += 1
         net.close()
     assert ran >= 60
+
+
+@pytest.mark.parametrize("case", ["nine_full", "long_corridor_full", "delft_prefix"])
+def test_recent_history_mode_gives_the_same_numbers(case):
+    """PEDN_HIST_RECENT keeps inflow / cumulative_inflow whole and everything else as short rings: the complete arrays must
+    equal the golden, and at several stops the entries still inside every ring must, too; older entries are refused."""
+    g = Golden(case)
+    net = build_network(g, n_replicas=2, replica_offset=g.replica, rng_seed=g.seed, rng_mode=g.mode, history="recent")
+    e = net.engine()
+    T1 = e.T + 1
+    rows = {name: e.history_rows(LINK_FIELDS[name][0]) for name in ALL_FIELDS}
+    assert rows["inflow"] == T1 and rows["cumulative_inflow"] == T1 and rows["sending_flow"] == 4 and rows["density"] == 4
+    assert rows["travel_time"] < T1 and rows["cumulative_outflow"] < T1
+    stops = sorted({min(g.steps - 1, s) for s in (3, 17, 60, g.steps - 1)})
+    t = 1
+    for stop in stops:
+        while t <= stop:
+            net.network_loading(t)
+            for mut in g.mutations:
+                if mut[0] == t:
+                    apply_mutation(net, mut)
+            t += 1
+        for name in ALL_FIELDS:
+            fid = LINK_FIELDS[name][0]
+            newest = stop - 1 if name in ("sending_flow", "receiving_flow") else stop     # S / R of step t are entries t - 1
+            lo = max(0, newest - rows[name] + 2) if rows[name] < T1 else 0
+            mine = e.read_block(fid, lo, newest + 1)[:, :e.n_links, 0].T
+            assert np.array_equal(mine, g.state(name)[:, lo:newest + 1]), (name, stop)
+        lk = net.links[tuple(g.static("link_uv")[0])]
+        assert lk.density[stop] == g.state("density")[0, stop]
+        if stop > 10:
+            with pytest.raises(IndexError):
+                lk.density[stop - 6]
+            col = np.asarray(lk.speed)
+            assert np.isnan(col[stop - 6]) and col[stop] == g.state("speed")[0, stop]
+    assert e.error_flags()[0] == 0
+    net.close()

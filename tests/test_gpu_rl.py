@@ -196,3 +196,25 @@ def test_step_device_with_torch_imported_first():
             "t._step_device_check(); print('ok')")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("case", ["rl_nine_opt3", "rl_corridor_opt1", "rl_nine_opt5g2"])
+def test_recent_history_mode_serves_the_rl_step(case):
+    """The batched RL step reads nothing older than the rings of PEDN_HIST_RECENT hold: same observations and rewards."""
+    g = Golden(case)
+    rl = g.info["rl"]
+    net = build_network(g, n_replicas=1, replica_offset=g.replica, rng_seed=g.seed, history="recent")
+    env = VecPedNetEnv(g.info["scenario"], n_envs=1, obs_mode=rl["obs_mode"], normalize_obs=rl["normalize"],
+                       action_gap=rl["action_gap"], network=net)
+    acts, ref_obs, ref_rew = g.state("rl_actions"), g.state("rl_obs"), g.state("rl_rewards")
+    for k in range(rl["env_steps"]):
+        obs, rew, *_ = env.step(acts[k:k + 1])
+        assert np.array_equal(obs[0], ref_obs[k]) and np.array_equal(rew[0], ref_rew[k]), k
+    e = net.engine()
+    last = g.steps - 1
+    ci = e.read_block(LINK_FIELDS["cumulative_inflow"][0], 0, last + 1)[:, :e.n_links, 0].T
+    assert np.array_equal(ci, g.state("cumulative_inflow")[:, :last + 1])
+    env.reset()
+    obs, rew, *_ = env.step(acts[0:1])          # the rings start over with the episode
+    assert np.array_equal(obs[0], ref_obs[0])
+    env.close()
