@@ -34,7 +34,7 @@ struct CorrRec {  // one lane group of link_kernel: both directions of a corrido
 // word k) and broadcast with v_readlane -- see turn_frac_body.
 #define PEDN_TF_LDS_ROWS 64    // LDS rows (64 lanes x 8 bytes) of one workgroup = 4 rows of dynamic nodes, shared out by the host
 #define PEDN_TROW_WORDS 128
-#define PEDN_TF_COOP_GROUPS 4   // rows with more multi-entry groups get a workgroup of their own (see turn_frac_body)
+#define PEDN_TF_COOP_GROUPS 8   // rows with more multi-entry groups get a workgroup of their own (see turn_frac_body)
 // row record, PEDN_TROW_WORDS words (m = -1: padding):
 //   [0] m  [1] first turn of the row  [2] first group (index into tgrp_words / 32)  [3] number of multi-entry groups
 //   [4] Q0  [5] Q1: the row's (turn, od) products  [6] n_used outgoing links below  [7] some of them is a separator

@@ -47,10 +47,12 @@ f, w = counters(pf), counters(pw)
 summary = {"calibration": {"known_read_bytes": cal_read_bytes, "FETCH_SIZE_bytes": cal_f, "fetch_factor": fetch_factor,
                            "known_write_bytes": cal_write_bytes, "WRITE_SIZE_bytes": cal_w, "write_factor": write_factor},
            "kernels": {}}
-for k in ("node_kernel", "link_kernel", "turn_prob_kernel"):
+for k in ("node_kernel", "link_kernel", "link_turn_kernel", "turn_frac_kernel"):
     if k not in f:
         continue
     fr, wr = f[k][warmup:], w[k][warmup:]
+    if not fr or not wr:
+        continue
     rd = st.mean(fr) * 1024 * round(fetch_factor, 2)
     wt = st.mean(wr) * 1024 * round(write_factor, 2)
     summary["kernels"][k] = {"launches_averaged": len(fr), "FETCH_SIZE_KiB_mean": st.mean(fr), "WRITE_SIZE_KiB_mean": st.mean(wr),
