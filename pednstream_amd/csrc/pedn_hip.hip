@@ -43,6 +43,9 @@ struct pedn_sim {
   double* d_turn_tab = nullptr;
   RlView rl{};
   bool rl_ready = false;
+  bool rl_fold = false;   // gater-only agent set: pedn_rl_step lets node_kernel apply the actions (no launch of rl_apply_kernel)
+  std::vector<SlotRec> h_slot_rec;
+  SlotRec* d_slot_rec = nullptr;
   std::vector<double> h_front_u, h_back_u, h_tf_u;
   double *d_front_u = nullptr, *d_back_u = nullptr, *d_tf_u = nullptr;
   std::vector<int32_t> h_node_dyn, h_slot_dyn;  // per node: dynamic; per slot: SlotRec.dyn (0 static, 1 turn_frac_kernel, 2 tabulated)
@@ -584,7 +587,10 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     s->fuse_tp = 1;
     if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
+    for (SlotRec& R : rec) R.act = -1;
+    s->h_slot_rec = rec;
     TRY(upload(s, rec.data(), rec.size(), &v.slot_rec));
+    s->d_slot_rec = const_cast<SlotRec*>(v.slot_rec);
   }
   // ---- dynamic state
   {
@@ -898,8 +904,11 @@ static node_kernel_fn node_kernel_for(const pedn_sim* s) {
 // t+1 (models with softmax groups) and the RL observations / rewards of t (observe >= 0: the accumulate flag of
 // rl_observe; only pedn_rl_step asks for it).  ev != nullptr: per-launch start/stop events {turn_prob, node, link} for
 // pedn_profile_step.  Returns 1 through *observed when the observations were part of the launch.
-static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe = -1, bool* observed = nullptr) {
+static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe = -1, bool* observed = nullptr,
+                       const double* fold_actions = nullptr) {
   DevView& v = s->v;
+  DevView vn = v;                 // node_kernel's view: with the action rows when it applies the gater actions itself
+  vn.rl_actions = fold_actions;
   const unsigned rgroups = (unsigned)(v.RS / 64);
   const bool groups = v.n_trow > 0, fused = groups && s->fuse_tp;
   const bool obs_fused = observe >= 0 && s->rl_ready && s->fuse_obs;
@@ -913,7 +922,7 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     else launch(turn_frac_kernel<false>, dim3(nb), dim3(256), 0, v, t);
     s->tp_ran = 1;
   }
-  launch(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 2, v, t);
+  launch(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 2, vn, t);
   const unsigned nlb = v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2) + 255) / 256) : 0u;
   if (fused || obs_fused) {
     const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;
@@ -1211,6 +1220,30 @@ int pedn_rl_configure(pedn_sim* s, const pedn_rl_desc* d, int32_t* n_actions, in
       }
   }
   if ((rc = push_uniform(s)) != PEDN_OK) return rc;
+  {  // a gater action (back gate of outgoing link l of the gater node = front gate of its reverse) is consumed by exactly one
+     // wave of node_kernel, the slot (lin = reverse(l), lout = l): that wave can apply it.  A separator's width is read at both
+     // ends of its corridor, so agent sets with a separator keep the separate rl_apply_kernel launch.
+    bool only_gaters = true;
+    for (SlotRec& R : s->h_slot_rec) R.act = -1;
+    for (int a = 0, slot = 0; a < d->n_agents; ++a) {
+      const int n = d->agent_link_ptr[a + 1] - d->agent_link_ptr[a];
+      if (d->agent_type[a] == 0) { only_gaters = false; slot += 1; continue; }
+      for (int i = 0; i < n; ++i, ++slot) {
+        const int l = d->agent_links[d->agent_link_ptr[a] + i];
+        int hits = 0;
+        for (SlotRec& R : s->h_slot_rec)
+          if (R.node >= 0 && R.lout == l && R.lin < v.L) { R.act = slot; ++hits; }
+        if (hits != 1) only_gaters = false;
+      }
+    }
+    HIP_TRY(s, hipStreamSynchronize(s->stream));
+    HIP_TRY(s, hipMemcpy(s->d_slot_rec, s->h_slot_rec.data(), s->h_slot_rec.size() * sizeof(SlotRec), hipMemcpyHostToDevice));
+    s->rl_fold = only_gaters;
+    if (const char* f = getenv("PEDN_RL_FOLD")) s->rl_fold = s->rl_fold && atoi(f) != 0;
+    v.rl_A = A;
+    v.rl_max_delta_gate = d->max_delta_gate;
+    v.rl_actions = nullptr;
+  }
   s->rl_ready = true;
   if (n_actions) *n_actions = A;
   if (n_obs) *n_obs = O;
@@ -1253,12 +1286,28 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (action_gap < 1 || t < 1 || t + action_gap - 1 > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
   int rc = PEDN_OK;
-  if (actions && (rc = pedn_rl_apply_actions(s, actions, on_device)) != PEDN_OK) return rc;
+  if (!s->rl_ready) return fail(s, PEDN_E_ARG, "pedn_rl_configure has not been called");
   RlView& q = s->rl;
+  // gater-only agent sets: node_kernel of the first sub-step applies the actions (one launch less).  Not when the turning
+  // fractions of step t still have to be computed by their own launch in front of node_kernel: their capacity fallback reads
+  // the gate widths the actions are about to change (path_finder.py:575-576).
+  const double* fold = nullptr;
+  if (actions) {
+    const bool stand_alone_tf = s->v.n_trow > 0 && s->tp_ready != t;
+    if (s->rl_fold && !stand_alone_tf) {
+      HIP_TRY(s, hipSetDevice(s->device));
+      if (on_device) fold = actions;
+      else {
+        HIP_TRY(s, hipMemcpyAsync(q.actions, actions, (size_t)s->v.R * q.A * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(s, hipStreamSynchronize(s->stream));  // the host buffer is borrowed for the call only
+        fold = q.actions;
+      }
+    } else if ((rc = pedn_rl_apply_actions(s, actions, on_device)) != PEDN_OK) return rc;
+  }
   for (int k = 0; k < action_gap; ++k) {
     const bool last = k == action_gap - 1;
     bool observed = false;
-    launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed);
+    launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr);
     HIP_TRY(s, hipGetLastError());
     if (!observed) {
       if ((rc = pedn_rl_observe(s, t + k, k > 0, last ? obs : nullptr, last ? rewards : nullptr)) != PEDN_OK) return rc;

@@ -47,6 +47,7 @@ __device__ __forceinline__ T* rowp(T* base, int t, int col, int cols, int RS, in
   return base + (((size_t)t * (size_t)cols + (size_t)col) * (size_t)RS + (size_t)r0);
 }
 __device__ __forceinline__ float clip01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+__device__ __forceinline__ double clip_d(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }  // np.clip
 // Link parameters as seen by one lane: the shared record, or (PR) the replica's own k_critical / k_jam / free-flow speed
 // and the quantities derived from them on the host.
 template <bool PR>
@@ -593,6 +594,19 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       x.back_out = bu == bu ? bu : v.back[(size_t)lout * RS + r];
       x.sepw_in = Pin.sep ? v.sepw[(size_t)lin * RS + r] : 0.0;
       x.sepw_out = Pout.sep ? v.sepw[(size_t)lout * RS + r] : 0.0;
+      if (v.rl_actions != nullptr && W.act >= 0 && r < v.R) {
+        // ActionApplier for a gater (rl/builders.py:313-352: clip_gater_action_value + back_gate_width setter, link.py:121-126),
+        // done by the one wave that consumes the width: back gate of its outgoing link = front gate of its incoming link
+        double a = v.rl_actions[(size_t)r * v.rl_A + W.act];
+        if (a == a) {  // NaN: this agent was given no action
+          const double cur = x.back_out;
+          if (fabs(a - cur) > v.rl_max_delta_gate) a = cur + clip_d(a - cur, -v.rl_max_delta_gate, v.rl_max_delta_gate);
+          a = clip_d(a, 0.0, Pout.width);
+          x.back_out = x.front_in = a;
+          v.back[(size_t)lout * RS + r] = a;
+          v.front[(size_t)lin * RS + r] = a;
+        }
+      }
       if (kind == 1) {
 #pragma unroll
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
@@ -853,7 +867,6 @@ struct RlView {
   double max_delta_sep, max_delta_gate, min_sep;
 };
 
-__device__ __forceinline__ double clip_d(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }  // np.clip
 
 // ActionApplier (builders.py:281-352): one lane per (action slot, replica)
 __global__ void rl_apply_kernel(DevView v, RlView q) {

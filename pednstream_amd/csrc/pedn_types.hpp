@@ -20,7 +20,8 @@ struct LinkP {  // static per-link parameters, wave-uniform on the device
 struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything static it needs, fetched by ONE scalar load burst
   // dyn: where the slot's row of turning fractions comes from -- 0 tf / tf_u (default or imposed), 1 tfd[t & 1] (turn_frac_kernel),
   // 2 turn_tab[t] / turn_tab_r (every product constant: replica-independent, tabulated and renormalised on the host)
-  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, pad0, pad1;
+  // act: action slot of the batched RL step that sets this slot's gate (back gate of lout = front gate of lin), -1 none
+  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, act, pad1;
   LinkP Pin, Pout;  // parameters of the incoming / outgoing link of the slot (unused for a virtual pair)
 };
 
@@ -87,4 +88,8 @@ struct DevView {
   // flow looks back an unbounded, data-dependent number of steps into them), the others are rings of mask + 1 rows.
   int32_t m64[7], m32[6];
   int32_t hist;
+  // gater actions applied inside node_kernel (pedn_rl_step, gater-only agent sets): row-major [R][rl_A] widths, NaN = no action
+  const double* rl_actions;
+  int32_t rl_A;
+  double rl_max_delta_gate;
 };
