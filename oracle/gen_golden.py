@@ -170,7 +170,7 @@ def randnet_case(case, name, rand_seed, steps=None, replica=0, np_seed=20261003)
                                        "mutations": [], "randomize_network_seed": rand_seed})
 
 
-def native_ensemble(case, name, n_runs=64, times=(100, 200, 300, 400, 498)):
+def native_ensemble(case, name, n_runs=64, times=(100, 200, 300, 400, 498), demand_fn=None):
     """G6: the reference under its OWN numpy RNG, many seeds -> per-run densities / cumulative inflows at a few
     times plus each run's demand.  Used to check that the injected RNG contract (different stream, approximate binomial and
     normal transforms) reproduces the reference's ensemble statistics, not just itself."""
@@ -179,6 +179,10 @@ def native_ensemble(case, name, n_runs=64, times=(100, 200, 300, 400, 498)):
     for k in range(n_runs):
         np.random.seed(5000 + k)
         net = ref["env"].NetworkEnvGenerator().create_network(name)
+        if demand_fn is not None:                       # e.g. a heavier demand than the yaml's: busy links, congested branches
+            for nid, node in net.nodes.items():
+                if node.demand is not None and nid in net.origin_nodes:
+                    node.demand = demand_fn(net.simulation_steps, k)
         for t in range(1, net.simulation_steps):
             net.network_loading(t)
         links = list(net.links.values())
@@ -415,6 +419,8 @@ CASES.update({
                                            mutations=[(t, "back_gate_delta", 3, 5, -0.1) for t in range(100, 109)]),
     "output_corridor": lambda: output_case("output_corridor", "long_corridor", mutations=[(150, "separator_set", 2, 3, 1.25)]),
     "g6_nine_native": lambda: native_ensemble("g6_nine_native", "nine_intersections"),
+    "g6_melbourne_heavy_native": lambda: native_ensemble("g6_melbourne_heavy_native", "melbourne", n_runs=24,
+                                                         demand_fn=lambda T, k: replica_demand(T, 300 + k, base=60.0, peak=120.0)),
     "randnet_i45_a": lambda: randnet_case("randnet_i45_a", "45_intersections", 3, steps=150),
     "randnet_i45_b": lambda: randnet_case("randnet_i45_b", "45_intersections", 8, steps=150, replica=2),
     "randnet_nine": lambda: randnet_case("randnet_nine", "nine_intersections", 5, steps=200, replica=1),

@@ -308,7 +308,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   v.replica_offset = (uint32_t)replica_offset;
   v.meanfield = rng_mode == PEDN_RNG_MEANFIELD;
   v.n_grp = m->n_grp;
-  if (const char* d = getenv("PEDN_DBG")) v.dbg = atoi(d);
+  if (const char* d = getenv("PEDN_TF_GENERAL")) v.dbg = atoi(d);  // diagnostics: 1 general softmax path, 2 general row-sum path
   s->n_nodes = N; s->n_turns = m->n_turns; s->n_demand = m->n_demand; s->n_od = m->n_od; s->n_ent = m->n_ent;
   s->node_turn_ptr.assign(m->node_turn_ptr, m->node_turn_ptr + N + 1);
   s->h_node_slot_ptr.assign(m->node_slot_ptr, m->node_slot_ptr + N + 1);
@@ -428,6 +428,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.cost > b.cost; });
     std::vector<Row> packed;
     std::vector<int> lds_base;
+    int lds_limit = PEDN_TF_LDS_ROWS;  // diagnostics: PEDN_TF_LDS_LIMIT=n gives a row at most n LDS rows (the rest goes to ent_p)
+    if (const char* d = getenv("PEDN_TF_LDS_LIMIT")) lds_limit = std::max(0, std::min(atoi(d), PEDN_TF_LDS_ROWS));
     {
       std::vector<char> taken(rows.size(), 0);
       for (size_t a0 = 0; a0 < rows.size(); ++a0) {
@@ -440,7 +442,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         int fill = 0, cnt = 0;
         for (size_t k = a0; k < rows.size() && cnt < 4; ++k) {
           if (taken[k] || rows[k].groups > PEDN_TF_COOP_GROUPS) continue;
-          const int need = std::min(rows[k].need, PEDN_TF_LDS_ROWS);
+          const int need = std::min(rows[k].need, lds_limit);
           if (k != a0 && fill + need > PEDN_TF_LDS_ROWS) continue;
           taken[k] = 1;
           packed.push_back(rows[k]);
@@ -472,7 +474,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       }
       std::vector<int> used;  // outgoing slots this row's multi-entry groups refer to
       int n_prob = 0, n_g = 0, any_sep = 0, over = 0;
-      const int lds_rows = std::min(packed[ri].need, PEDN_TF_LDS_ROWS);
+      const int lds_rows = std::min(packed[ri].need, lds_limit);
       for (int g = m->node_grp_ptr[n]; g < m->node_grp_ptr[n + 1]; ++g) {
         const int a = m->grp_ent_ptr[g], b = m->grp_ent_ptr[g + 1];
         if (grp_row[g] != i || b - a < 1 || (b - a == 1 && shortcut)) continue;

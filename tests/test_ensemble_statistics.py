@@ -10,13 +10,19 @@ from pednstream_amd import NetworkEnvGenerator
 from pednstream_amd.flatten import flatten_network
 
 
-def test_contract_rng_reproduces_native_rng_ensemble_statistics():
-    z = np.load(f"{GOLDEN}/g6_nine_native.npz")
+import pytest
+
+
+@pytest.mark.parametrize("case,scenario", [("g6_nine_native", "nine_intersections"), ("g6_melbourne_heavy_native", "melbourne")])
+def test_contract_rng_reproduces_native_rng_ensemble_statistics(case, scenario):
+    """nine_intersections under its yaml demand (64 runs) and melbourne under 12x its demand (24 runs: busy links, release
+    binomials with n > 16 -- the normal approximation --, diffusion, congested branch)."""
+    z = np.load(f"{GOLDEN}/{case}.npz")
     times = z["times"]
     ref_k, ref_c = z["density"].astype(np.float64), z["cumulative_inflow"]       # [runs, links, times]
     R = ref_k.shape[0]
     np.random.seed(0)
-    net = NetworkEnvGenerator(DATA).create_network("nine_intersections", verbose=False)
+    net = NetworkEnvGenerator(DATA).create_network(scenario, verbose=False)
     model = flatten_network(net)
     L = model["n_links"]
     mine_k, mine_c = np.empty_like(ref_k), np.empty_like(ref_c)

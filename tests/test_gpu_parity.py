@@ -182,9 +182,11 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
 
-    def history(fuse, waves, stepwise):
+    def history(fuse, waves, stepwise, general="0", lds_limit="64"):
         monkeypatch.setenv("PEDN_FUSE_TP", fuse)
         monkeypatch.setenv("PEDN_NODE_WAVES", waves)
+        monkeypatch.setenv("PEDN_TF_GENERAL", general)        # 3: softmax groups and row sums through their general (any-size) paths
+        monkeypatch.setenv("PEDN_TF_LDS_LIMIT", lds_limit)    # 1: all but one probability of a row overflow from LDS into HBM
         np.random.seed(7)
         net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=64, rng_seed=11)
         if stepwise:
@@ -204,10 +206,11 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
         return out
 
     ref = history("0", "6", False)
-    for fuse, waves, stepwise in (("1", "6", False), ("0", "8", False), ("1", "8", True)):
-        got = history(fuse, waves, stepwise)
+    for variant in (("1", "6", False), ("0", "8", False), ("1", "8", True), ("1", "8", False, "3", "64"), ("0", "8", False, "1", "1"),
+                    ("1", "8", True, "0", "0")):
+        got = history(*variant)
         for f in ALL_FIELDS:
-            assert np.array_equal(ref[f], got[f]), (fuse, waves, stepwise, f)
+            assert np.array_equal(ref[f], got[f]), (variant, f)
 
 
 def test_full_size_melbourne_1024_invariants():
@@ -366,8 +369,8 @@ def test_per_replica_widths_and_turning_fractions_via_replica_scope():
     net.close()
 
 
-@pytest.mark.parametrize("fuse_tp", ["1", "0"])
-def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, monkeypatch):
+@pytest.mark.parametrize("fuse_tp,general,lds_limit", [("1", "0", "64"), ("0", "0", "64"), ("1", "3", "1")])
+def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, monkeypatch):
     """(with the next step's turn probabilities fused into the link update launch, and launched on their own: nine of the
     networks put separator links into softmax groups, whose density the fused launch re-derives)
     40 random scenarios (random trees + chords, all three fundamental diagrams, separators, controllers, activity,
@@ -379,6 +382,8 @@ def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, monkeypatch):
     from pednstream_amd import Network
 
     monkeypatch.setenv("PEDN_FUSE_TP", fuse_tp)
+    monkeypatch.setenv("PEDN_TF_GENERAL", general)
+    monkeypatch.setenv("PEDN_TF_LDS_LIMIT", lds_limit)
     ran = 0
     for seed in range(3000, 3040):
         adj, params, origins, dests = random_case(seed)
