@@ -32,6 +32,7 @@ struct pedn_sim {
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
   int node_waves = 8;  // register budget of node_kernel, see pedn_create
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
+  int link_ns = 1;     // segments of 128 replicas per lane of the link update (launch_step); PEDN_LINK_NS=1|2
   int fuse_tp = 0;     // the link update and the next step's turn probabilities share one launch (launch_step)
   int tp_ran = 0;      // launch_step launched the stand-alone turn_frac_kernel (pedn_profile_step)
   int tp_ready = -1;   // step whose turning fractions are in tfd[step & 1] (written by link_turn_kernel of the step before), -1: none
@@ -589,6 +590,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     s->fuse_tp = 1;
     if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
+    if (const char* f = getenv("PEDN_LINK_NS")) s->link_ns = atoi(f) == 2 ? 2 : 1;
     for (SlotRec& R : rec) R.act = -1;
     s->h_slot_rec = rec;
     TRY(upload(s, rec.data(), rec.size(), &v.slot_rec));
@@ -925,24 +927,30 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     s->tp_ran = 1;
   }
   launch(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 2, vn, t);
-  const unsigned nlb = v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / 2) + 255) / 256) : 0u;
+  // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
+  const int ns = (!v.pr && s->link_ns == 2 && v.RS % 256 == 0) ? 2 : 1;
+  const unsigned nlb = v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / (2 * ns)) + 255) / 256) : 0u;
   if (fused || obs_fused) {
     const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;
     const unsigned nob = obs_fused ? (unsigned)s->rl.n_agents * rgroups : 0u;  // one block per (agent, 64 replicas)
     RlView q = s->rl;
     if (!obs_fused) q.n_agents = 0;
     const int acc = observe > 0 ? 1 : 0;
+    const dim3 grid(nlb + ntb + nob), block(256);
     if (obs_fused) {
-      if (v.pr) launch(link_turn_kernel<true, true>, dim3(nlb + ntb + nob), dim3(256), 4, v, t, nlb, ntb, q, acc);
-      else launch(link_turn_kernel<false, true>, dim3(nlb + ntb + nob), dim3(256), 4, v, t, nlb, ntb, q, acc);
+      if (v.pr) launch(link_turn_kernel<true, true, 1>, grid, block, 4, v, t, nlb, ntb, q, acc);
+      else if (ns == 2) launch(link_turn_kernel<false, true, 2>, grid, block, 4, v, t, nlb, ntb, q, acc);
+      else launch(link_turn_kernel<false, true, 1>, grid, block, 4, v, t, nlb, ntb, q, acc);
     } else {
-      if (v.pr) launch(link_turn_kernel<true, false>, dim3(nlb + ntb), dim3(256), 4, v, t, nlb, ntb, q, acc);
-      else launch(link_turn_kernel<false, false>, dim3(nlb + ntb), dim3(256), 4, v, t, nlb, ntb, q, acc);
+      if (v.pr) launch(link_turn_kernel<true, false, 1>, grid, block, 4, v, t, nlb, ntb, q, acc);
+      else if (ns == 2) launch(link_turn_kernel<false, false, 2>, grid, block, 4, v, t, nlb, ntb, q, acc);
+      else launch(link_turn_kernel<false, false, 1>, grid, block, 4, v, t, nlb, ntb, q, acc);
     }
     if (fused) s->tp_ready = t + 1;
   } else if (v.n_pairs_corr > 0) {
     if (v.pr) launch(link_kernel_pr, dim3(nlb), dim3(256), 4, v, t);
-    else launch(link_kernel, dim3(nlb), dim3(256), 4, v, t);
+    else if (ns == 2) launch(link_kernel<2>, dim3(nlb), dim3(256), 4, v, t);
+    else launch(link_kernel<1>, dim3(nlb), dim3(256), 4, v, t);
   }
   if (observed) *observed = obs_fused;
   s->last_t = t;

@@ -758,69 +758,85 @@ __device__ __forceinline__ float2 ld2(const float* p, size_t i) { return *reinte
 __device__ __forceinline__ void st2(double* p, size_t i, double a, double b) { *reinterpret_cast<double2*>(p + i) = make_double2(a, b); }
 __device__ __forceinline__ void st2(float* p, size_t i, float a, float b) { *reinterpret_cast<float2*>(p + i) = make_float2(a, b); }
 
-// Network.update_link_states (network.py:257-264).  One lane = both directions of one corridor for TWO adjacent replicas:
-// every history access is a 16-byte (f64) or 8-byte (f32) vector access, i.e. 1 KiB / 512 B per wave instruction.
+// Network.update_link_states (network.py:257-264).  One lane = both directions of one corridor for two adjacent replicas in
+// each of NS segments of 128 replicas: every history access is a 16-byte (f64) or 8-byte (f32) vector access, i.e. 1 KiB /
+// 512 B contiguous per wave instruction.  NS = 2 halves the number of waves for the same work (twice the loads in flight per
+// wave): used inside link_turn_kernel, where the turning-fraction waves compete for the wave slots.
+template <int NS>
 __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
-  const int RS = v.RS, L = v.L, Lall = v.Lall, H = RS / 2;
+  const int RS = v.RS, L = v.L, Lall = v.Lall, H = RS / (2 * NS);  // lanes per corridor
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)H));
-  const int r = 2 * (int)(gid % (size_t)H);
+  const int lh = (int)(gid % (size_t)H);
+  const int r0 = (lh / 64) * (128 * NS) + (lh % 64) * 2;  // first replica of segment 0; segment s starts 128 s further
   if (p >= v.n_pairs_corr) return;
   const CorrRec& C = v.corr_rec[p];  // wave-uniform
   const int a = C.a, b = C.b;
   const LinkP& Pa = C.Pa;
   const LinkP& Pb = C.Pb;
   const bool win = t >= v.W;
-  // ---- loads
-  const double2 ina = ld2(v.f64[F_IN], at(R64(F_IN, t), a, Lall, RS, r)), outa = ld2(v.f64[F_OUT], at(R64(F_OUT, t), a, Lall, RS, r));
-  const double2 inb = ld2(v.f64[F_IN], at(R64(F_IN, t), b, Lall, RS, r)), outb = ld2(v.f64[F_OUT], at(R64(F_OUT, t), b, Lall, RS, r));
-  const float2 pa = ld2(v.f32[G_N], at(R32(G_N, t - 1), a, L, RS, r)), pb = ld2(v.f32[G_N], at(R32(G_N, t - 1), b, L, RS, r));
-  const float2 rsa = ld2(v.rsum, (size_t)a * RS + r), rsb = ld2(v.rsum, (size_t)b * RS + r);
-  const float2 oa = win ? ld2(v.f32[G_TT], at(R32(G_TT, t - v.W), a, L, RS, r)) : make_float2(0.f, 0.f);
-  const float2 ob = win ? ld2(v.f32[G_TT], at(R32(G_TT, t - v.W), b, L, RS, r)) : make_float2(0.f, 0.f);
   const double bua = v.back_u[a], bub = v.back_u[b];
-  double2 wa = make_double2(Pa.width, Pa.width), wb = make_double2(Pb.width, Pb.width), fa = make_double2(0, 0), fb = make_double2(0, 0);
-  if (Pa.sep) { wa = ld2(v.sepw, (size_t)a * RS + r); fa = ld2(v.sepnp, (size_t)a * RS + r); }
-  if (Pb.sep) { wb = ld2(v.sepw, (size_t)b * RS + r); fb = ld2(v.sepnp, (size_t)b * RS + r); }
-  double2 ga = Pa.sep ? wa : make_double2(bua, bua), gb = Pb.sep ? wb : make_double2(bub, bub);  // recorded width (link.py:188 / :451-452)
-  if (!Pa.sep && !(bua == bua)) ga = ld2(v.back, (size_t)a * RS + r);
-  if (!Pb.sep && !(bub == bub)) gb = ld2(v.back, (size_t)b * RS + r);
-  // ---- per replica arithmetic (link.py:133-136, then update_speeds)
-  float na[2], nb[2], ka[2], kb[2];
-  SpeedOut sa[2], sb[2];
-  const double dina[2] = {ina.x - outa.x, ina.y - outa.y}, dinb[2] = {inb.x - outb.x, inb.y - outb.y};
-  const float pav[2] = {pa.x, pa.y}, pbv[2] = {pb.x, pb.y};
-  const double wav[2] = {wa.x, wa.y}, wbv[2] = {wb.x, wb.y}, fav[2] = {fa.x, fa.y}, fbv[2] = {fb.x, fb.y};
-  const float rsav[2] = {rsa.x, rsa.y}, rsbv[2] = {rsb.x, rsb.y}, oav[2] = {oa.x, oa.y}, obv[2] = {ob.x, ob.y};
+  // ---- loads of all segments
+  double2 ina[NS], outa[NS], inb[NS], outb[NS], wa[NS], wb[NS], fa[NS], fb[NS], ga[NS], gb[NS];
+  float2 pa[NS], pb[NS], rsa[NS], rsb[NS], oa[NS], ob[NS];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    na[j] = (float)((double)pav[j] + dina[j]);
-    nb[j] = (float)((double)pbv[j] + dinb[j]);
-    // a separator width held as np.float64 turns the division into binary64 (PEDN_W_SEP_NUMPY)
-    ka[j] = (Pa.sep && fav[j] != 0.0) ? (float)((double)na[j] / (Pa.length * wav[j])) : na[j] / (float)(Pa.length * wav[j]);
-    kb[j] = (Pb.sep && fbv[j] != 0.0) ? (float)((double)nb[j] / (Pb.length * wbv[j])) : nb[j] / (float)(Pb.length * wbv[j]);
-    sa[j] = speed_calc(v, Pa, a, t, r + j, ka[j], kb[j], rsav[j], oav[j]);
-    sb[j] = speed_calc(v, Pb, b, t, r + j, kb[j], ka[j], rsbv[j], obv[j]);
+  for (int s = 0; s < NS; ++s) {
+    const int r = r0 + 128 * s;
+    ina[s] = ld2(v.f64[F_IN], at(R64(F_IN, t), a, Lall, RS, r)); outa[s] = ld2(v.f64[F_OUT], at(R64(F_OUT, t), a, Lall, RS, r));
+    inb[s] = ld2(v.f64[F_IN], at(R64(F_IN, t), b, Lall, RS, r)); outb[s] = ld2(v.f64[F_OUT], at(R64(F_OUT, t), b, Lall, RS, r));
+    pa[s] = ld2(v.f32[G_N], at(R32(G_N, t - 1), a, L, RS, r)); pb[s] = ld2(v.f32[G_N], at(R32(G_N, t - 1), b, L, RS, r));
+    rsa[s] = ld2(v.rsum, (size_t)a * RS + r); rsb[s] = ld2(v.rsum, (size_t)b * RS + r);
+    oa[s] = win ? ld2(v.f32[G_TT], at(R32(G_TT, t - v.W), a, L, RS, r)) : make_float2(0.f, 0.f);
+    ob[s] = win ? ld2(v.f32[G_TT], at(R32(G_TT, t - v.W), b, L, RS, r)) : make_float2(0.f, 0.f);
+    wa[s] = make_double2(Pa.width, Pa.width); wb[s] = make_double2(Pb.width, Pb.width);
+    fa[s] = make_double2(0, 0); fb[s] = make_double2(0, 0);
+    if (Pa.sep) { wa[s] = ld2(v.sepw, (size_t)a * RS + r); fa[s] = ld2(v.sepnp, (size_t)a * RS + r); }
+    if (Pb.sep) { wb[s] = ld2(v.sepw, (size_t)b * RS + r); fb[s] = ld2(v.sepnp, (size_t)b * RS + r); }
+    ga[s] = Pa.sep ? wa[s] : make_double2(bua, bua);  // recorded width (link.py:188 / :451-452)
+    gb[s] = Pb.sep ? wb[s] : make_double2(bub, bub);
+    if (!Pa.sep && !(bua == bua)) ga[s] = ld2(v.back, (size_t)a * RS + r);
+    if (!Pb.sep && !(bub == bub)) gb[s] = ld2(v.back, (size_t)b * RS + r);
   }
-  // ---- stores
-  st2(v.f32[G_N], at(R32(G_N, t), a, L, RS, r), na[0], na[1]);
-  st2(v.f32[G_N], at(R32(G_N, t), b, L, RS, r), nb[0], nb[1]);
-  st2(v.f32[G_K], at(R32(G_K, t), a, L, RS, r), ka[0], ka[1]);
-  st2(v.f32[G_K], at(R32(G_K, t), b, L, RS, r), kb[0], kb[1]);
-  st2(v.f32[G_V], at(R32(G_V, t), a, L, RS, r), sa[0].spd, sa[1].spd);
-  st2(v.f32[G_V], at(R32(G_V, t), b, L, RS, r), sb[0].spd, sb[1].spd);
-  st2(v.f32[G_TT], at(R32(G_TT, t), a, L, RS, r), sa[0].tt, sa[1].tt);
-  st2(v.f32[G_TT], at(R32(G_TT, t), b, L, RS, r), sb[0].tt, sb[1].tt);
-  st2(v.f32[G_LF], at(R32(G_LF, t), a, L, RS, r), sa[0].lf, sa[1].lf);
-  st2(v.f32[G_LF], at(R32(G_LF, t), b, L, RS, r), sb[0].lf, sb[1].lf);
-  if (win) {
-    st2(v.f32[G_ATT], at(R32(G_ATT, t), a, L, RS, r), sa[0].att, sa[1].att);
-    st2(v.f32[G_ATT], at(R32(G_ATT, t), b, L, RS, r), sb[0].att, sb[1].att);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int r = r0 + 128 * s;
+    // ---- per replica arithmetic (link.py:133-136, then update_speeds)
+    float na[2], nb[2], ka[2], kb[2];
+    SpeedOut sa[2], sb[2];
+    const double dina[2] = {ina[s].x - outa[s].x, ina[s].y - outa[s].y}, dinb[2] = {inb[s].x - outb[s].x, inb[s].y - outb[s].y};
+    const float pav[2] = {pa[s].x, pa[s].y}, pbv[2] = {pb[s].x, pb[s].y};
+    const double wav[2] = {wa[s].x, wa[s].y}, wbv[2] = {wb[s].x, wb[s].y}, fav[2] = {fa[s].x, fa[s].y}, fbv[2] = {fb[s].x, fb[s].y};
+    const float rsav[2] = {rsa[s].x, rsa[s].y}, rsbv[2] = {rsb[s].x, rsb[s].y}, oav[2] = {oa[s].x, oa[s].y}, obv[2] = {ob[s].x, ob[s].y};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      na[j] = (float)((double)pav[j] + dina[j]);
+      nb[j] = (float)((double)pbv[j] + dinb[j]);
+      // a separator width held as np.float64 turns the division into binary64 (PEDN_W_SEP_NUMPY)
+      ka[j] = (Pa.sep && fav[j] != 0.0) ? (float)((double)na[j] / (Pa.length * wav[j])) : na[j] / (float)(Pa.length * wav[j]);
+      kb[j] = (Pb.sep && fbv[j] != 0.0) ? (float)((double)nb[j] / (Pb.length * wbv[j])) : nb[j] / (float)(Pb.length * wbv[j]);
+      sa[j] = speed_calc(v, Pa, a, t, r + j, ka[j], kb[j], rsav[j], oav[j]);
+      sb[j] = speed_calc(v, Pb, b, t, r + j, kb[j], ka[j], rsbv[j], obv[j]);
+    }
+    // ---- stores
+    st2(v.f32[G_N], at(R32(G_N, t), a, L, RS, r), na[0], na[1]);
+    st2(v.f32[G_N], at(R32(G_N, t), b, L, RS, r), nb[0], nb[1]);
+    st2(v.f32[G_K], at(R32(G_K, t), a, L, RS, r), ka[0], ka[1]);
+    st2(v.f32[G_K], at(R32(G_K, t), b, L, RS, r), kb[0], kb[1]);
+    st2(v.f32[G_V], at(R32(G_V, t), a, L, RS, r), sa[0].spd, sa[1].spd);
+    st2(v.f32[G_V], at(R32(G_V, t), b, L, RS, r), sb[0].spd, sb[1].spd);
+    st2(v.f32[G_TT], at(R32(G_TT, t), a, L, RS, r), sa[0].tt, sa[1].tt);
+    st2(v.f32[G_TT], at(R32(G_TT, t), b, L, RS, r), sb[0].tt, sb[1].tt);
+    st2(v.f32[G_LF], at(R32(G_LF, t), a, L, RS, r), sa[0].lf, sa[1].lf);
+    st2(v.f32[G_LF], at(R32(G_LF, t), b, L, RS, r), sb[0].lf, sb[1].lf);
+    if (win) {
+      st2(v.f32[G_ATT], at(R32(G_ATT, t), a, L, RS, r), sa[0].att, sa[1].att);
+      st2(v.f32[G_ATT], at(R32(G_ATT, t), b, L, RS, r), sb[0].att, sb[1].att);
+    }
+    st2(v.rsum, (size_t)a * RS + r, sa[0].rs, sa[1].rs);
+    st2(v.rsum, (size_t)b * RS + r, sb[0].rs, sb[1].rs);
+    // the record is initialised to `width` (link.py:56), so an unchanged gate needs no store
+    if (ga[s].x != Pa.width || ga[s].y != Pa.width || v.hist) st2(v.f64[F_GATE], at(R64(F_GATE, t), a, L, RS, r), ga[s].x, ga[s].y);
+    if (gb[s].x != Pb.width || gb[s].y != Pb.width || v.hist) st2(v.f64[F_GATE], at(R64(F_GATE, t), b, L, RS, r), gb[s].x, gb[s].y);
   }
-  st2(v.rsum, (size_t)a * RS + r, sa[0].rs, sa[1].rs);
-  st2(v.rsum, (size_t)b * RS + r, sb[0].rs, sb[1].rs);
-  // the record is initialised to `width` (link.py:56), so an unchanged gate needs no store
-  if (ga.x != Pa.width || ga.y != Pa.width || v.hist) st2(v.f64[F_GATE], at(R64(F_GATE, t), a, L, RS, r), ga.x, ga.y);
-  if (gb.x != Pb.width || gb.y != Pb.width || v.hist) st2(v.f64[F_GATE], at(R64(F_GATE, t), b, L, RS, r), gb.x, gb.y);
 }
 
 // Same update with per-replica link parameters: one replica per lane (the parameters live in vector registers).
@@ -854,7 +870,8 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
   if (gb != Pb.width || v.hist) v.f64[F_GATE][at(R64(F_GATE, t), b, L, RS, r)] = gb;
 }
 
-__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) { link_body(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
+template <int NS>
+__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) { link_body<NS>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
 __global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) { link_pr_body(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
 
 // ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------
@@ -1012,8 +1029,8 @@ __global__ __launch_bounds__(256) void rl_observe_kernel(DevView v, RlView q, in
 // The parts are independent (the second and third re-derive what the first is about to store), so they run side by side;
 // as separate launches each of them cost 5-9 us, most of it the fixed cost of a launch.
 // (OBS = false: the instantiation ordinary stepping uses carries neither the LDS nor the registers of the third part)
-template <bool PR, bool OBS>
-__global__ __launch_bounds__(256) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, RlView q, int accumulate) {
+template <bool PR, bool OBS, int NS>
+__global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, RlView q, int accumulate) {
   // the turning-fraction workgroups come first in dispatch order: theirs are the long dependent chains of the launch (the
   // heaviest rows lead), the link update behind them is bound by memory throughput and fills the machine around them
   if (blockIdx.x < n_tp_blocks) {
@@ -1021,7 +1038,7 @@ __global__ __launch_bounds__(256) void link_turn_kernel(DevView v, int t, unsign
   } else if (blockIdx.x < n_tp_blocks + n_link_blocks) {
     const size_t gid = (size_t)(blockIdx.x - n_tp_blocks) * blockDim.x + threadIdx.x;
     if (PR) link_pr_body(v, t, gid);
-    else link_body(v, t, gid);
+    else link_body<NS>(v, t, gid);
   } else if (OBS) {
     rl_observe_body<true>(v, q, t, accumulate, blockIdx.x - n_link_blocks - n_tp_blocks);
   }
