@@ -52,11 +52,15 @@ extern "C" {
 #define PEDN_F_INDEX 4u       /* history index outside [-(T+1), T] (IndexError in the reference) */
 #define PEDN_F_NEG_BINOM 8u   /* binomial with n < 0               (numpy ValueError at link.py:382) */
 #define PEDN_F_SAME_STEP 16u  /* look-back of 0 steps: the reference result depends on node iteration order */
+#define PEDN_F_LP 32u         /* node LP (assign_flows_type 'optimal') did not terminate: `res.success` false, node.py:267 */
 
 /* RNG modes (oracle/rng_contract.py) */
 #define PEDN_RNG_PHILOX 0
 #define PEDN_RNG_MEANFIELD 1 /* binomial -> floor(n*p), normal -> 0 */
 
+#define PEDN_NODE_CLASSIC 0
+#define PEDN_NODE_OPTIMAL 1
+#define PEDN_LP_PENALTY 1e-2 /* Node.w, node.py:14 */
 #define PEDN_HIST_FULL 0
 #define PEDN_HIST_RECENT 1
 
@@ -144,6 +148,13 @@ typedef struct pedn_model_desc {
    * the moving-average window + 2, everything else the last 4.  Same numbers step for step (the batched RL environment
    * reads nothing older); pedn_read of an entry that has left its ring fails.  16 B + a few rows instead of 80 B. */
   int32_t history_mode;
+
+  /* PEDN_NODE_CLASSIC: RegularNode.solve('classic') (node.py:272-300).  PEDN_NODE_OPTIMAL: assign_flows_type 'optimal', the
+   * linear programme of node.py:249-271 (maximise the total flow minus 0.01 x the deviation from the turning fractions under
+   * the sending / receiving constraints) solved per (node, replica) by a dense primal simplex with Bland's rule.  The
+   * reference hands the same programme to scipy/HiGHS; the optimum is degenerate, so the two agree in the objective value,
+   * not necessarily in the vertex: parity for this mode is objective-level only (unpinned). */
+  int32_t node_model;
 } pedn_model_desc;
 
 typedef struct pedn_sim pedn_sim;

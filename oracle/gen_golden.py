@@ -200,6 +200,57 @@ def native_ensemble(case, name, n_runs=64, times=(100, 200, 300, 400, 498), dema
     print(f"{case}: {os.path.getsize(path) / 1024:.0f} KiB ({n_runs} native-RNG runs)")
 
 
+def lp_case(case, name, steps=60, np_seed=20261003, max_solves=600):
+    """assign_flows_type 'optimal': every linear programme the REAL reference hands to scipy/HiGHS during the first steps of a
+    run (RegularNode.solve, node.py:249-271) -- its inputs (degree, s, r, turning fractions) and HiGHS's optimal value and
+    resulting q -- so that the simplex of oracle/pedn_oracle.c can be checked against the reference's own solves."""
+    ref = rh.load_reference()
+    node_mod = ref["node"]
+    real_linprog = node_mod.linprog
+    last = {}
+
+    def recording_linprog(*a, **k):
+        res = real_linprog(*a, **k)
+        last["res"] = res
+        return res
+
+    real_solve = node_mod.RegularNode.solve
+    rec = []
+
+    def recording_solve(self, s, r, type="classic"):
+        tf = np.array(self.turning_fractions, dtype=np.float64)
+        real_solve(self, s, r, type=type)
+        if type == "optimal" and len(rec) < max_solves:
+            res = last["res"]
+            rec.append((self.source_num, np.array(s, dtype=np.float64), np.array(r, dtype=np.float64), tf, float(res.fun), bool(res.success),
+                        np.array(self.q, dtype=np.float64)))
+
+    node_mod.linprog = recording_linprog
+    node_mod.RegularNode.solve = recording_solve
+    try:
+        np.random.seed(np_seed)
+        gen = ref["env"].NetworkEnvGenerator()
+        gen.network_data = gen.load_network_data(name)
+        gen.config["params"]["assign_flows_type"] = "optimal"
+        net = gen.create_network(name)
+        for t in range(1, steps):
+            net.network_loading(t)
+    finally:
+        node_mod.linprog = real_linprog
+        node_mod.RegularNode.solve = real_solve
+    M = max(x[0] for x in rec)
+    n = len(rec)
+    out = {"m": np.array([x[0] for x in rec], dtype=np.int32), "s": np.zeros((n, M)), "r": np.zeros((n, M)), "tf": np.zeros((n, M * (M - 1))),
+           "fun": np.array([x[4] for x in rec]), "success": np.array([x[5] for x in rec]), "q": np.zeros((n, 2 * M)),
+           "info_json": np.array(json.dumps({"scenario": name, "steps": steps, "numpy": np.__version__, "scipy": __import__("scipy").__version__}))}
+    for k, (m, s_, r_, tf, fun, ok, q) in enumerate(rec):
+        out["s"][k, :m], out["r"][k, :m], out["tf"][k, :m * (m - 1)], out["q"][k, :2 * m] = s_, r_, tf, q
+    path = os.path.join(OUT, case + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{case}: {os.path.getsize(path) / 1024:.0f} KiB, {n} linear programmes of the reference, degrees {sorted(set(out['m'].tolist()))}, "
+          f"{int((out['s'].sum(axis=1) > 0).sum())} with traffic")
+
+
 def rl_case(case, name, obs_mode="option3", normalize=False, action_gap=1, env_steps=150, seed=0, replica=0,
             np_seed=20261003, action_seed=1, skip_prob=0.0, init_widths=None):
     """Config #5 caller: the reference's ActionApplier / ObservationBuilder / reward (rl/builders.py,
@@ -418,6 +469,8 @@ CASES.update({
     "output_six_node": lambda: output_case("output_six_node", "od_flow_example",
                                            mutations=[(t, "back_gate_delta", 3, 5, -0.1) for t in range(100, 109)]),
     "output_corridor": lambda: output_case("output_corridor", "long_corridor", mutations=[(150, "separator_set", 2, 3, 1.25)]),
+    "lp_nine": lambda: lp_case("lp_nine", "nine_intersections", steps=70),
+    "lp_i45": lambda: lp_case("lp_i45", "45_intersections", steps=40, max_solves=900),
     "g6_nine_native": lambda: native_ensemble("g6_nine_native", "nine_intersections"),
     "g6_melbourne_heavy_native": lambda: native_ensemble("g6_melbourne_heavy_native", "melbourne", n_runs=24,
                                                          demand_fn=lambda T, k: replica_demand(T, 300 + k, base=60.0, peak=120.0)),

@@ -490,6 +490,78 @@ static void dyn_tf(pedn_oracle* o, int n, int t) {
   }
 }
 
+/* RegularNode.solve('optimal') (node.py:249-271): min c.x with c = (-1 per flow, w per penalty variable), x >= 0,
+ *   rows 0..m-1      sum_j f_ij <= s_i          rows m..2m-1   sum_i f_ij <= r_j                      (get_matrix_A, :73-98)
+ *   rows 2m..2m+E-1  phi_e * sum_{j} f_(src e)j - f_e + p_e^+ - p_e^- = 0                               (update_matrix_A_eq, :110-137)
+ * by a dense primal simplex on the full tableau, Bland's rule, starting from the feasible basis {slacks, p^+}.  The HIP
+ * engine runs the same operations in the same order (pedn_kernels.hpp: lp_solve).  Returns 0 on success; g[e] = floor(f_e). */
+int pedn_oracle_lp(int m, const double* s, const double* r, const double* tf, double* x_out, double* g) {
+  const int E = m * (m - 1), R = 2 * m + E, N = 3 * E + 2 * m, W = N + 1;
+  const double tol = 1e-9, w = PEDN_LP_PENALTY;
+  double* T = (double*)calloc((size_t)(R + 1) * W, sizeof(double));
+  int* basis = (int*)malloc((size_t)R * sizeof(int));
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) {
+      if (i == j) continue;
+      const int e = i * (m - 1) + (j < i ? j : j - 1);
+      T[(size_t)i * W + e] = 1.0;
+      T[(size_t)(m + j) * W + e] = 1.0;
+    }
+  for (int k = 0; k < 2 * m; ++k) {
+    T[(size_t)k * W + 3 * E + k] = 1.0;
+    T[(size_t)k * W + N] = k < m ? s[k] : r[k - m];
+    basis[k] = 3 * E + k;
+  }
+  for (int e = 0; e < E; ++e) {
+    const int i = e / (m - 1), k = 2 * m + e;
+    for (int c = i * (m - 1); c < (i + 1) * (m - 1); ++c) T[(size_t)k * W + c] = tf[e];
+    T[(size_t)k * W + e] = tf[e] - 1;
+    T[(size_t)k * W + E + 2 * e] = 1.0;
+    T[(size_t)k * W + E + 2 * e + 1] = -1.0;
+    basis[k] = E + 2 * e;
+  }
+  /* objective row: reduced costs; the starting basis holds the p^+ (cost w) */
+  for (int c = 0; c < N; ++c) T[(size_t)R * W + c] = c < E ? -1.0 : (c < 3 * E ? w : 0.0);
+  for (int k = 2 * m; k < R; ++k)
+    for (int c = 0; c <= N; ++c) T[(size_t)R * W + c] -= w * T[(size_t)k * W + c];
+  int status = 1;
+  for (int it = 0; it < 40 * (R + N); ++it) {
+    int j = -1;
+    for (int c = 0; c < N; ++c)
+      if (T[(size_t)R * W + c] < -tol) { j = c; break; }
+    if (j < 0) { status = 0; break; }
+    int i = -1;
+    double best = 0.0;
+    for (int k = 0; k < R; ++k) {
+      const double a = T[(size_t)k * W + j];
+      if (a > tol) {
+        const double ratio = T[(size_t)k * W + N] / a;
+        if (i < 0 || ratio < best - 1e-12 || (fabs(ratio - best) <= 1e-12 && basis[k] < basis[i])) { best = ratio; i = k; }
+      }
+    }
+    if (i < 0) break; /* unbounded: cannot happen, the flows are bounded by s */
+    const double piv = T[(size_t)i * W + j];
+    for (int c = 0; c <= N; ++c) T[(size_t)i * W + c] = T[(size_t)i * W + c] / piv;
+    for (int k = 0; k <= R; ++k) {
+      if (k == i) continue;
+      const double f = T[(size_t)k * W + j];
+      if (f == 0.0) continue;
+      for (int c = 0; c <= N; ++c) T[(size_t)k * W + c] = T[(size_t)k * W + c] - f * T[(size_t)i * W + c];
+    }
+    basis[i] = j;
+  }
+  for (int e = 0; e < E; ++e) g[e] = 0.0;
+  if (x_out) for (int c = 0; c < N; ++c) x_out[c] = 0.0;
+  if (status == 0)
+    for (int k = 0; k < R; ++k) {
+      if (x_out) x_out[basis[k]] = T[(size_t)k * W + N];
+      if (basis[k] < E) g[basis[k]] = floor(T[(size_t)k * W + N]);
+    }
+  free(T);
+  free(basis);
+  return status;
+}
+
 static void node_step(pedn_oracle* o, int n, int t) {
   const pedn_model_desc* m = &o->m;
   int s0 = m->node_slot_ptr[n], mdeg = m->node_slot_ptr[n + 1] - s0;
@@ -517,6 +589,17 @@ static void node_step(pedn_oracle* o, int n, int t) {
     qo[0] = qi[1] = s[0] < r[1] ? s[0] : r[1];
     qo[1] = qi[0] = s[1] < r[0] ? s[1] : r[0];
     if (qo[0] < 0.0 || qo[1] < 0.0) o->flags |= PEDN_F_NEG_FLOW;
+  } else if (m->node_model == PEDN_NODE_OPTIMAL) { /* RegularNode.solve('optimal'), node.py:249-271 */
+    double g[PEDN_MAX_DEGREE * (PEDN_MAX_DEGREE - 1)];
+    if (pedn_oracle_lp(mdeg, s, r, o->tf + m->node_turn_ptr[n], NULL, g) != 0) o->flags |= PEDN_F_LP;
+    for (int i = 0; i < mdeg; ++i) qo[i] = qi[i] = 0.0;
+    for (int i = 0; i < mdeg; ++i)
+      for (int j = 0; j < mdeg; ++j) {
+        if (i == j) continue;
+        const double f = g[i * (mdeg - 1) + (j < i ? j : j - 1)];
+        qo[i] += f; qi[j] += f;
+      }
+    for (int i = 0; i < mdeg; ++i) { if (!(qo[i] > 0.0)) qo[i] = 0.0; if (!(qi[i] > 0.0)) qi[i] = 0.0; }
   } else { /* RegularNode.solve('classic'), node.py:272-300 */
     const double* tf = o->tf + m->node_turn_ptr[n];
     double ps[PEDN_MAX_DEGREE][PEDN_MAX_DEGREE], D[PEDN_MAX_DEGREE];

@@ -44,6 +44,7 @@ struct pedn_sim {
   double* d_turn_tab = nullptr;
   RlView rl{};
   bool rl_ready = false;
+  bool node_lp = false;   // PEDN_NODE_OPTIMAL: the node LP instead of the classic rule
   bool rl_fold = false;   // gater-only agent set: pedn_rl_step lets node_kernel apply the actions (no launch of rl_apply_kernel)
   std::vector<SlotRec> h_slot_rec;
   SlotRec* d_slot_rec = nullptr;
@@ -271,6 +272,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     if (m->grp_ent_ptr[g + 1] - m->grp_ent_ptr[g] > PEDN_MAX_DEGREE - 1) return fail(nullptr, PEDN_E_ARG, "softmax group too large");
 
   if (m->history_mode != PEDN_HIST_FULL && m->history_mode != PEDN_HIST_RECENT) return fail(nullptr, PEDN_E_ARG, "unknown history_mode");
+  if (m->node_model != PEDN_NODE_CLASSIC && m->node_model != PEDN_NODE_OPTIMAL) return fail(nullptr, PEDN_E_ARG, "unknown node_model");
 
   HIP_TRY(nullptr, hipSetDevice(device));
   pedn_sim* s = new pedn_sim();
@@ -591,7 +593,19 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
     if (const char* f = getenv("PEDN_LINK_NS")) s->link_ns = atoi(f) == 2 ? 2 : 1;
-    for (SlotRec& R : rec) R.act = -1;
+    for (SlotRec& R : rec) { R.act = -1; R.lp = -1; }
+    s->node_lp = m->node_model == PEDN_NODE_OPTIMAL;
+    if (s->node_lp) {  // tableau workspace: one per (regular node, replica group), sized for the largest such node
+      int n_lp = 0, max_m = 0;
+      for (SlotRec& R : rec)
+        if (R.node >= 0 && R.kind == 1 && R.slot == 0) { R.lp = n_lp++; max_m = std::max(max_m, R.m); }
+      const int E = max_m * (max_m - 1), rows = 2 * max_m + E, cols = 3 * E + 2 * max_m;
+      v.lp_stride = (size_t)(rows + 1) * (cols + 1) * 64;
+      v.lp_bstride = (size_t)rows * 64;
+      const size_t waves = (size_t)std::max(n_lp, 1) * (v.RS / 64);
+      TRY(dalloc(s, waves * v.lp_stride, &v.lp_ws));
+      TRY(dalloc(s, waves * v.lp_bstride, &v.lp_basis));
+    }
     s->h_slot_rec = rec;
     TRY(upload(s, rec.data(), rec.size(), &v.slot_rec));
     s->d_slot_rec = const_cast<SlotRec*>(v.slot_rec);
@@ -900,6 +914,7 @@ int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
 
 typedef void (*node_kernel_fn)(DevView, int);
 static node_kernel_fn node_kernel_for(const pedn_sim* s) {
+  if (s->node_lp) return s->v.pr ? node_kernel<true, 8, true> : node_kernel<false, 8, true>;
   if (s->v.pr) return s->node_waves == 8 ? node_kernel<true, 8> : node_kernel<true, 6>;
   return s->node_waves == 8 ? node_kernel<false, 8> : node_kernel<false, 6>;
 }

@@ -517,14 +517,96 @@ __global__ __launch_bounds__(256) void turn_frac_kernel(DevView v, int t) {
   turn_frac_body<PR, false>(v, t, blockIdx.x);
 }
 
+// RegularNode.solve('optimal') (node.py:249-271) for 64 replicas of one node, one LP per lane: dense primal simplex on the
+// full tableau with Bland's rule, the operations of oracle/pedn_oracle.c: pedn_oracle_lp in the same order (see there for
+// the programme).  The tableau of lane `lane` lives in HBM, element (k, c) at T[(k * W + c) * 64 + lane]; `tile` holds the
+// node's turning fractions on entry ([i * m + j][64]) and floor(flow i -> j) on return; s / r: [slot][64] in LDS.
+// Not a fast path: no scenario of the reference selects this node model.
+__device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double* s, const double* r, double* tile, int lane) {
+  const int E = m * (m - 1), R = 2 * m + E, N = 3 * E + 2 * m, W = N + 1;
+  const double tol = 1e-9, w = PEDN_LP_PENALTY;
+  auto el = [&](int k, int c) -> double& { return T[((size_t)k * W + c) * 64 + lane]; };
+  for (int x = 0; x < (R + 1) * W; ++x) T[(size_t)x * 64 + lane] = 0.0;
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) {
+      if (i == j) continue;
+      const int e = i * (m - 1) + (j < i ? j : j - 1);
+      el(i, e) = 1.0;
+      el(m + j, e) = 1.0;
+    }
+  for (int k = 0; k < 2 * m; ++k) {
+    el(k, 3 * E + k) = 1.0;
+    el(k, N) = k < m ? s[k * 64 + lane] : r[(k - m) * 64 + lane];
+    B[k * 64 + lane] = 3 * E + k;
+  }
+  for (int e = 0; e < E; ++e) {
+    const int i = e / (m - 1), jj = e % (m - 1), k = 2 * m + e;
+    const double tfe = tile[(i * m + (jj < i ? jj : jj + 1)) * 64 + lane];
+    for (int c = i * (m - 1); c < (i + 1) * (m - 1); ++c) el(k, c) = tfe;
+    el(k, e) = tfe - 1;
+    el(k, E + 2 * e) = 1.0;
+    el(k, E + 2 * e + 1) = -1.0;
+    B[k * 64 + lane] = E + 2 * e;
+  }
+  for (int c = 0; c < N; ++c) el(R, c) = c < E ? -1.0 : (c < 3 * E ? w : 0.0);
+  for (int k = 2 * m; k < R; ++k)
+    for (int c = 0; c <= N; ++c) el(R, c) = el(R, c) - w * el(k, c);
+  bool done = false, ok = true;
+  for (int it = 0; it < 40 * (R + N); ++it) {
+    int j = -1;
+    if (!done)
+      for (int c = 0; c < N; ++c)
+        if (j < 0 && el(R, c) < -tol) j = c;
+    if (j < 0) done = true;
+    if (!__any(!done)) break;
+    if (!done) {
+      int i = -1, bi = 0;
+      double best = 0.0;
+      for (int k = 0; k < R; ++k) {
+        const double a = el(k, j);
+        if (a > tol) {
+          const double ratio = el(k, N) / a;
+          const int bk = B[k * 64 + lane];
+          if (i < 0 || ratio < best - 1e-12 || (fabs(ratio - best) <= 1e-12 && bk < bi)) { best = ratio; i = k; bi = bk; }
+        }
+      }
+      if (i < 0) { done = true; ok = false; }
+      else {
+        const double piv = el(i, j);
+        for (int c = 0; c <= N; ++c) el(i, c) = el(i, c) / piv;
+        for (int k = 0; k <= R; ++k) {
+          if (k == i) continue;
+          const double f = el(k, j);
+          if (f == 0.0) continue;
+          for (int c = 0; c <= N; ++c) el(k, c) = el(k, c) - f * el(i, c);
+        }
+        B[i * 64 + lane] = j;
+      }
+    }
+  }
+  if (!done) ok = false;
+  for (int x = 0; x < m * m; ++x) tile[x * 64 + lane] = 0.0;
+  if (ok)
+    for (int k = 0; k < R; ++k) {
+      const int e = B[k * 64 + lane];
+      if (e < E) {
+        const int i = e / (m - 1), jj = e % (m - 1);
+        tile[(i * m + (jj < i ? jj : jj + 1)) * 64 + lane] = floor(el(k, N));
+      }
+    }
+  return ok;
+}
+
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
 // WAVES = waves per SIMD the register allocation aims at.  6: no spills, 3 blocks per CU -- best where the launch is bound by
 // HBM throughput (melbourne: 26.4 us against 28.0).  8: 64 VGPRs with 12 spilled, 4 blocks per CU -- best where it is bound by
 // latency, i.e. with dynamic junctions (delft: 36.6 us against 39.9).  pedn_create picks one per model.
-template <bool PR, int WAVES>
+// LP: the node model is the linear programme of assign_flows_type 'optimal' instead of the classic proportional rule.
+template <bool PR, int WAVES, bool LP = false>
 __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   __shared__ double sPS[64 * 64];  // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
   __shared__ double sR[8 * 64];    // receiving flow of each wave's outgoing link
+  __shared__ double sS[LP ? 8 * 64 : 1];  // LP: sending flow of each wave's incoming link
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
   const int RS = v.RS, L = v.L, Lall = v.Lall;
@@ -632,19 +714,26 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
         if (jj < m - 1) {
           const int j = jj < slot ? jj : jj + 1;
-          sPS[(size_t)(base + slot * m + j) * 64 + lane] = tfr[jj] * s_i;
+          sPS[(size_t)(base + slot * m + j) * 64 + lane] = LP ? tfr[jj] : tfr[jj] * s_i;
         }
       }
     } else {
       sPS[(size_t)(base + slot) * 64 + lane] = s_i;
     }
     sR[wave * 64 + lane] = r_i;
+    if (LP) sS[wave * 64 + lane] = s_i;
   }
   PH(5, r_i);
   __syncthreads();
   PH(6, lane);
 
-  if (active && kind == 1) {
+  if (LP) {
+    if (active && kind == 1 && slot == 0) {  // one wave solves the node's programme for its 64 replicas
+      const size_t w = (size_t)W.lp * gridDim.x + blockIdx.x;
+      if (!lp_solve(v.lp_ws + w * v.lp_stride, v.lp_basis + w * v.lp_bstride, m, &sS[wave * 64], &sR[wave * 64], &sPS[(size_t)base * 64], lane))
+        fl |= PEDN_F_LP;
+    }
+  } else if (active && kind == 1) {
     // column `slot`: D_j = sum_i P[i][j] s_i (i ascending), g_ij = floor(min(P s, r_j * (P s / D_j)))  (node.py:286-298)
     double D = 0.0;
     bool first = true;
@@ -677,6 +766,11 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
 #pragma unroll
       for (int j = 0; j < PEDN_MAX_DEGREE; ++j)
         if (j < m && j != slot) qo += sPS[(size_t)(base + slot * m + j) * 64 + lane];
+      if (LP) {  // q = A_ub @ floor(x): the column sums were not formed by a column pass
+#pragma unroll
+        for (int k = 0; k < PEDN_MAX_DEGREE; ++k)
+          if (k < m && k != slot) qi += sPS[(size_t)(base + k * m + slot) * 64 + lane];
+      }
       if (!(qo > 0.0)) qo = 0.0;  // np.maximum(0, flows), node.py:299
       if (!(qi > 0.0)) qi = 0.0;
     } else {  // OneToOneNode.solve (node.py:230-242), not floored

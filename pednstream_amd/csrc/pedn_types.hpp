@@ -21,7 +21,8 @@ struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything sta
   // dyn: where the slot's row of turning fractions comes from -- 0 tf / tf_u (default or imposed), 1 tfd[t & 1] (turn_frac_kernel),
   // 2 turn_tab[t] / turn_tab_r (every product constant: replica-independent, tabulated and renormalised on the host)
   // act: action slot of the batched RL step that sets this slot's gate (back gate of lout = front gate of lin), -1 none
-  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, act, pad1;
+  // lp: index of the node among those that solve the node LP (assign_flows_type 'optimal'), on the node's slot 0, else -1
+  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, act, lp;
   LinkP Pin, Pout;  // parameters of the incoming / outgoing link of the slot (unused for a virtual pair)
 };
 
@@ -92,4 +93,8 @@ struct DevView {
   const double* rl_actions;
   int32_t rl_A;
   double rl_max_delta_gate;
+  // node LP (PEDN_NODE_OPTIMAL): per (LP node, replica group) a tableau of lp_stride doubles x 64 lanes and lp_bstride basis ids
+  double* lp_ws;
+  int32_t* lp_basis;
+  size_t lp_stride, lp_bstride;
 };

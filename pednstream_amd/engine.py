@@ -17,7 +17,8 @@ ERROR_BITS = {1: "negative sending flow (ValueError, link.py:345-346,365-366)",
               2: "negative flows at a node (Warning, node.py:192-194,218-219,237-238)",
               4: "history index out of range (IndexError)",
               8: "binomial with n < 0 (ValueError, link.py:382)",
-              16: "zero-step look-back: result depends on node iteration order in the reference"}
+              16: "zero-step look-back: result depends on node iteration order in the reference",
+              32: "node LP (assign_flows_type 'optimal') did not terminate"}
 
 _I32P, _F64P, _F32P = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float)
 
@@ -44,7 +45,7 @@ class ModelDesc(C.Structure):
         ("node_up_ptr", _I32P), ("up_slot", _I32P), ("up_od_ptr", _I32P), ("upod_od", _I32P), ("node_grp_ptr", _I32P),
         ("grp_ent_ptr", _I32P), ("grp_allphys", _I32P), ("grp_node", _I32P), ("ent_link", _I32P), ("ent_dist", _F64P),
         ("turn_pair_ptr", _I32P), ("pair_ent", _I32P), ("pair_upod", _I32P),
-        ("history_mode", C.c_int32),
+        ("history_mode", C.c_int32), ("node_model", C.c_int32),
     ]
 
 
@@ -73,7 +74,7 @@ def build_model_desc(model: dict):
             keep.append(arr)
             setattr(desc, name, arr.ctypes.data_as(ctype))
         else:
-            setattr(desc, name, model.get(name, 0) if name == "history_mode" else model[name])
+            setattr(desc, name, model.get(name, 0) if name in ("history_mode", "node_model") else model[name])
     return desc, keep
 
 

@@ -22,7 +22,8 @@ def flatten_network(net) -> dict:
     L, N = len(links), len(nodes)
     T = int(net.simulation_steps)
     m = {"n_nodes": N, "n_links": L, "n_vlinks": int(net.n_vlinks), "T": T, "dt": float(net.unit_time),
-         "history_mode": {"full": 0, "recent": 1}[getattr(net, "history", "full")]}
+         "history_mode": {"full": 0, "recent": 1}[getattr(net, "history", "full")],
+         "node_model": {"classic": 0, "optimal": 1}[getattr(net, "assign_flows_type", "classic")]}
 
     # ---- nodes / slots -------------------------------------------------------------------------------------
     slot_ptr, turn_ptr = [0], [0]

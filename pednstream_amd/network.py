@@ -374,9 +374,10 @@ class Network:
         self.od_manager = None
         self.pos = pos
         self.assign_flows_type = params.get("assign_flows_type", "classic")
-        if self.assign_flows_type != "classic":
-            # 'optimal' is the scipy/HiGHS LP node model (node.py:249-271): out of scope for the HIP path
-            raise ValueError(f"Invalid type: {self.assign_flows_type} (only the 'classic' node model is implemented)")
+        if self.assign_flows_type not in ("classic", "optimal"):
+            raise ValueError(f"Invalid type: {self.assign_flows_type}")        # node.py:302
+        # 'optimal' (node.py:249-271) is the node LP; the device solves it with its own simplex, which agrees with the reference's
+        # scipy/HiGHS in the objective value, not necessarily in the (degenerate) vertex -- see include/pedn.h: node_model
         self.n_replicas = int(n_replicas)
         self.replica_offset = int(replica_offset)
         self.rng_seed, self.rng_mode, self.device = int(rng_seed), rng_mode, int(device)

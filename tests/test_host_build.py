@@ -113,13 +113,14 @@ def test_missing_scenario_raises_file_not_found():
         NetworkEnvGenerator(DATA).create_network("no_such_scenario")
 
 
-def test_optimal_node_model_is_rejected():
+def test_unknown_node_model_is_rejected():
     g = Golden("forky")
     from pednstream_amd import Network
 
-    p = dict(g.info["params"], assign_flows_type="optimal")
-    with pytest.raises(ValueError):
+    p = dict(g.info["params"], assign_flows_type="best")
+    with pytest.raises(ValueError):                       # node.py:302
         Network(np.array(g.info["adjacency"]), p, origin_nodes=[0, 4], verbose=False)
+    Network(np.array(g.info["adjacency"]), dict(g.info["params"], assign_flows_type="optimal"), origin_nodes=[0, 4], verbose=False)
 
 
 def test_array_statics_equal_the_scalar_expressions():
