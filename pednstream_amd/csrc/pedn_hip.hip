@@ -1113,7 +1113,7 @@ int pedn_set_link_params(pedn_sim* s, const double* kc, const double* kj, const 
   for (size_t i = 0; i < (size_t)v.L * v.R; ++i) {
     if (!(kj[i] > kc[i]) || !(kc[i] > 0.0) || !(vf[i] > 0.0)) return fail(s, PEDN_E_ARG, "need 0 < k_critical < k_jam and free_flow_speed > 0");
     if (fft[i] < 0 || tau_sw[i] < 0) return fail(s, PEDN_E_ARG, "negative look-back");
-    if (tau_sw[i] + 2 > s->rows64[F_CO]) return fail(s, PEDN_E_ARG, "shock-wave look-back longer than the cumulative_outflow ring (recent-history mode)");
+    if (v.hist && tau_sw[i] + 2 > s->rows64[F_CO]) return fail(s, PEDN_E_ARG, "shock-wave look-back longer than the cumulative_outflow ring (recent-history mode)");
   }
   int rc;
   const size_t n = (size_t)v.L * v.RS;

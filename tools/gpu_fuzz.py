@@ -22,12 +22,16 @@ from pednstream_amd.scenarios import ScenarioBatch, derive_statics_arrays
 ran = skipped = flagged = 0
 for seed in range(lo, hi):
     adj, params, origins, dests = random_case(seed)
+    if os.environ.get("PEDN_FUZZ_OPTIMAL"):          # the node LP instead of the classic rule (engine and oracle: the same simplex)
+        params["assign_flows_type"] = "optimal"
     np.random.seed(seed)
     try:
         net = Network(adj, copy.deepcopy(params), origin_nodes=origins, destination_nodes=dests, verbose=False, n_replicas=3, rng_seed=seed, replica_offset=seed % 5)
     except KeyError:
         skipped += 1; continue
     model = flatten_network(net)
+    if model["max_degree"] > 8:              # kernel limit (PEDN_MAX_DEGREE): pedn_create refuses such a junction
+        skipped += 1; continue
     T = params["simulation_steps"]
     models = [model] * 3
     if per_replica:
