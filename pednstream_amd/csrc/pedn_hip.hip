@@ -820,6 +820,7 @@ int pedn_set_od_weights(pedn_sim* s, int32_t od, const double* values, int32_t n
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemcpy((void*)(s->v.od_w + (size_t)od * s->v.T1), values, (size_t)n * 8, hipMemcpyHostToDevice));
   std::copy(values, values + n, s->h_od_w.begin() + (size_t)od * s->v.T1);
+  s->tp_ready = -1;  // fractions of the next step may already sit in tfd, computed with the old weights
   return tabulate_pair_pod(s);
 }
 

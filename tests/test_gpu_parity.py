@@ -449,3 +449,31 @@ def test_recent_history_mode_gives_the_same_numbers(case):
             assert np.isnan(col[stop - 6]) and col[stop] == g.state("speed")[0, stop]
     assert e.error_flags()[0] == 0
     net.close()
+
+
+def test_od_weights_changed_between_steps_take_effect_at_the_next_step():
+    """The turning fractions of step t + 1 are computed in the launch behind node_kernel(t); a setter in between that they
+    depend on (OD weights, back gate widths) must make the engine recompute them -- compared with the oracle doing the same."""
+    g = Golden("nine_full")
+    net = build_network(g, n_replicas=2, replica_offset=g.replica, rng_seed=g.seed)
+    model = flatten_network(net)
+    e = net.engine()
+    o = od.Oracle(model, seed=g.seed, replica=g.replica)
+    T1 = e.T + 1
+    rng = np.random.default_rng(5)
+    P = C.POINTER(C.c_double)
+    for t in range(1, 90):
+        net.network_loading(t)
+        o.step(t)
+        if t in (20, 21, 55):
+            for k in range(int(model["n_od"])):
+                w = rng.uniform(0.0, 10.0, T1)
+                e.set_od_weights(k, w)
+                o.L.pedn_oracle_set_od_weights(o.h, k, np.ascontiguousarray(w).ctypes.data_as(P), T1)
+    for name in ALL_FIELDS:
+        mine = e.read_block(LINK_FIELDS[name][0], 0, 90)[:, :e.n_links, 0].T
+        assert np.array_equal(mine, o.field(name)[:e.n_links, :90]), name
+    tf = np.concatenate([e.get_turning_fractions(nd.index, 0) for nd in net.nodes.values()])
+    assert np.array_equal(tf, o.tf())
+    assert not np.array_equal(o.field("inflow")[:e.n_links, :90], g.state("inflow")[:, :90])      # the change mattered
+    net.close()
