@@ -545,13 +545,21 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     v.n_pairs_corr = (int)cr.size();
     TRY(upload(s, cr.data(), cr.size(), &v.corr_rec));
   }
-  {  // bin nodes into blocks of 8 waves: first-fit over the nodes ordered by slot count decreasing, so that every block is
-    // full regardless of node degree.  The 8 waves of a block meet at two barriers; since the route-choice sums moved to
-    // turn_frac_kernel every slot wave costs about the same.
-    std::vector<int> order(N);
+  {  // bin nodes into blocks of 8 waves: first-fit over the nodes ordered by (expected load, slot count) decreasing, so that
+    // every block is full regardless of node degree.  The 8 waves of a block meet at two barriers, so a block lasts as long
+    // as its slowest wave, and the slow waves are those of busy links (look-backs, diffusion, binomial draws).  The junctions
+    // that many OD routes pass -- those with many (turn, od) products -- are the likely ones and go first (delft: 32.3 ->
+    // 31.6 us; PEDN_PACK_BY_LOAD=0 orders by slot count only).  Re-packing at run time by the cost the waves measure
+    // themselves (ticks up to the first barrier, sampled every 100 / 250 steps) was tried and changed nothing (30.5 us either
+    // way): the spread inside a block comes from step-to-step variation, not from which junctions share it.
+    std::vector<int> order(N), load(N, 0);
     for (int n = 0; n < N; ++n) order[n] = n;
     auto deg = [&](int n) { return m->node_slot_ptr[n + 1] - m->node_slot_ptr[n]; };
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return deg(a) > deg(b); });
+    bool by_load = true;
+    if (const char* f = getenv("PEDN_PACK_BY_LOAD")) by_load = atoi(f) != 0;
+    if (by_load)
+      for (int n = 0; n < N; ++n) load[n] = m->turn_pair_ptr[m->node_turn_ptr[n + 1]] - m->turn_pair_ptr[m->node_turn_ptr[n]];
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] != load[b] ? load[a] > load[b] : deg(a) > deg(b); });
     std::vector<std::vector<int>> bins;
     std::vector<int> fill;
     for (int n : order) {
