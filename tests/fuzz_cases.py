@@ -3,7 +3,9 @@ reference offline; here they only need this repository's own host code)."""
 import numpy as np
 
 
-def random_case(seed):
+def random_case(seed, short_links=False):
+    """short_links: about a third of the corridors are shorter than half a time step (tau = 0 and / or tau_shockwave = 0):
+    their look-backs reach into the step that is being computed, where the reference's result depends on its node order."""
     rng = np.random.default_rng(seed)
     n = int(rng.integers(5, 14))
     adj = np.zeros((n, n), dtype=int)
@@ -28,6 +30,11 @@ def random_case(seed):
             links[f"{i}_{j}"] = {"length": float(rng.uniform(35, 150)), "fd_type": str(rng.choice(["yperman", "greenshields", "smulders"]))}
         if rng.random() < 0.1:
             links.setdefault(f"{i}_{j}", {})["controller_type"] = "separator"
+    if short_links:
+        srng = np.random.default_rng(seed + 7919)          # its own stream: the ordinary cases stay what they were
+        for (i, j) in pairs:
+            if srng.random() < 0.35:
+                links.setdefault(f"{i}_{j}", {})["length"] = float(srng.uniform(0.6, 0.55 * dt))   # tt0 = length / v_f of a few seconds
     k = int(rng.integers(1, 4))
     nodes = rng.permutation(n)
     origins = [int(x) for x in nodes[:k]]
