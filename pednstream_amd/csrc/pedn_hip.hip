@@ -923,9 +923,13 @@ int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
 
 typedef void (*node_kernel_fn)(DevView, int);
 static node_kernel_fn node_kernel_for(const pedn_sim* s) {
-  if (s->node_lp) return s->v.pr ? node_kernel<true, 8, true> : node_kernel<false, 8, true>;
-  if (s->v.pr) return s->node_waves == 8 ? node_kernel<true, 8> : node_kernel<true, 6>;
-  return s->node_waves == 8 ? node_kernel<false, 8> : node_kernel<false, 6>;
+  const bool h = s->v.hist != 0;  // recent-history mode: the instantiations that mask the history rows
+  if (s->node_lp) return s->v.pr ? (h ? node_kernel<true, 8, true, true> : node_kernel<true, 8, true, false>)
+                                 : (h ? node_kernel<false, 8, true, true> : node_kernel<false, 8, true, false>);
+  if (s->v.pr) return s->node_waves == 8 ? (h ? node_kernel<true, 8, false, true> : node_kernel<true, 8, false, false>)
+                                         : (h ? node_kernel<true, 6, false, true> : node_kernel<true, 6, false, false>);
+  return s->node_waves == 8 ? (h ? node_kernel<false, 8, false, true> : node_kernel<false, 8, false, false>)
+                            : (h ? node_kernel<false, 6, false, true> : node_kernel<false, 6, false, false>);
 }
 
 // One step = node_kernel(t), then ONE launch with the link update of t and -- where they apply -- the turn probabilities of
@@ -946,8 +950,8 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   };
   if (groups && s->tp_ready != t) {  // first step of an episode, a repeated or an out-of-order step
     const unsigned nb = (unsigned)((v.n_trow + 3) / 4) * rgroups;  // one wave per (row of a dynamic node, 64 replicas)
-    if (v.pr) launch(turn_frac_kernel<true>, dim3(nb), dim3(256), 0, v, t);
-    else launch(turn_frac_kernel<false>, dim3(nb), dim3(256), 0, v, t);
+    if (v.pr) { if (v.hist) launch(turn_frac_kernel<true, true>, dim3(nb), dim3(256), 0, v, t); else launch(turn_frac_kernel<true, false>, dim3(nb), dim3(256), 0, v, t); }
+    else { if (v.hist) launch(turn_frac_kernel<false, true>, dim3(nb), dim3(256), 0, v, t); else launch(turn_frac_kernel<false, false>, dim3(nb), dim3(256), 0, v, t); }
     s->tp_ran = 1;
   }
   launch(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 2, vn, t);
@@ -961,20 +965,24 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     if (!obs_fused) q.n_agents = 0;
     const int acc = observe > 0 ? 1 : 0;
     const dim3 grid(nlb + ntb + nob), block(256);
+    // instantiation by (per-replica parameters, observations in the launch, segments per lane, recent-history mode)
+#define PEDN_LT(PR_, OBS_, NS_) do { if (v.hist) launch(link_turn_kernel<PR_, OBS_, NS_, true>, grid, block, 4, v, t, nlb, ntb, q, acc); \
+                                     else launch(link_turn_kernel<PR_, OBS_, NS_, false>, grid, block, 4, v, t, nlb, ntb, q, acc); } while (0)
     if (obs_fused) {
-      if (v.pr) launch(link_turn_kernel<true, true, 1>, grid, block, 4, v, t, nlb, ntb, q, acc);
-      else if (ns == 2) launch(link_turn_kernel<false, true, 2>, grid, block, 4, v, t, nlb, ntb, q, acc);
-      else launch(link_turn_kernel<false, true, 1>, grid, block, 4, v, t, nlb, ntb, q, acc);
+      if (v.pr) PEDN_LT(true, true, 1);
+      else if (ns == 2) PEDN_LT(false, true, 2);
+      else PEDN_LT(false, true, 1);
     } else {
-      if (v.pr) launch(link_turn_kernel<true, false, 1>, grid, block, 4, v, t, nlb, ntb, q, acc);
-      else if (ns == 2) launch(link_turn_kernel<false, false, 2>, grid, block, 4, v, t, nlb, ntb, q, acc);
-      else launch(link_turn_kernel<false, false, 1>, grid, block, 4, v, t, nlb, ntb, q, acc);
+      if (v.pr) PEDN_LT(true, false, 1);
+      else if (ns == 2) PEDN_LT(false, false, 2);
+      else PEDN_LT(false, false, 1);
     }
+#undef PEDN_LT
     if (fused) s->tp_ready = t + 1;
   } else if (v.n_pairs_corr > 0) {
-    if (v.pr) launch(link_kernel_pr, dim3(nlb), dim3(256), 4, v, t);
-    else if (ns == 2) launch(link_kernel<2>, dim3(nlb), dim3(256), 4, v, t);
-    else launch(link_kernel<1>, dim3(nlb), dim3(256), 4, v, t);
+    if (v.pr) { if (v.hist) launch(link_kernel_pr<true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel_pr<false>, dim3(nlb), dim3(256), 4, v, t); }
+    else if (ns == 2) { if (v.hist) launch(link_kernel<2, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel<2, false>, dim3(nlb), dim3(256), 4, v, t); }
+    else { if (v.hist) launch(link_kernel<1, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel<1, false>, dim3(nlb), dim3(256), 4, v, t); }
   }
   if (observed) *observed = obs_fused;
   s->last_t = t;
@@ -1308,7 +1316,8 @@ int pedn_rl_observe(pedn_sim* s, int32_t t, int32_t accumulate, float* obs, floa
   HIP_TRY(s, hipSetDevice(s->device));
   DevView& v = s->v;
   RlView& q = s->rl;
-  hipLaunchKernelGGL(rl_observe_kernel, dim3((unsigned)q.n_agents * (unsigned)(v.RS / 64)), dim3(256), 0, s->stream, v, q, t, accumulate);
+  if (v.hist) hipLaunchKernelGGL(rl_observe_kernel<true>, dim3((unsigned)q.n_agents * (unsigned)(v.RS / 64)), dim3(256), 0, s->stream, v, q, t, accumulate);
+  else hipLaunchKernelGGL(rl_observe_kernel<false>, dim3((unsigned)q.n_agents * (unsigned)(v.RS / 64)), dim3(256), 0, s->stream, v, q, t, accumulate);
   HIP_TRY(s, hipGetLastError());
   if (obs) HIP_TRY(s, hipMemcpyAsync(obs, q.obs, (size_t)v.R * q.O * sizeof(float), hipMemcpyDeviceToHost, s->stream));
   if (rewards) HIP_TRY(s, hipMemcpyAsync(rewards, q.rew, (size_t)v.R * q.n_agents * sizeof(float), hipMemcpyDeviceToHost, s->stream));

@@ -34,8 +34,11 @@ __device__ unsigned long long g_tphase[4096 * 8];  // turn_frac_body: [row][stam
 
 // History row of time index t: all T+1 rows are kept in full-record mode (mask = all ones); in recent-history mode
 // (PEDN_HIST_RECENT) the fields nothing looks far back into are rings of a power-of-two number of rows -- see pedn_create.
-#define R64(F, t) ((t) & v.m64[F])
-#define R32(G, t) ((t) & v.m32[G])
+// HIST is a template parameter of every kernel that touches a history: in full-record mode the index is the time index itself, so
+// the row arithmetic of accesses to different fields at the same time index is shared (one AND per access and field cost
+// node_kernel +57 % scalar instructions and ~1 us when the masks were applied unconditionally).
+#define R64(F, t) (HIST ? ((t) & v.m64[F]) : (t))
+#define R32(G, t) (HIST ? ((t) & v.m32[G]) : (t))
 
 __device__ __forceinline__ size_t at(int t, int col, int cols, int RS, int r) {
   return ((size_t)t * (size_t)cols + (size_t)col) * (size_t)RS + (size_t)r;
@@ -68,6 +71,7 @@ __device__ __forceinline__ int wrap_idx(int i, int T1, uint32_t& fl) {
 }
 
 // Link.get_density (link.py:190-197) / Separator.get_density (:427-428) at history index t
+template <bool HIST>
 __device__ __forceinline__ float dens_at(const DevView& v, const LinkP& P, int l, int t, int r) {
   if (P.sep) return v.f32[G_K][at(R32(G_K, t), l, v.L, v.RS, r)];
   float n = v.f32[G_N][at(R32(G_N, t), l, v.L, v.RS, r)] + v.f32[G_N][at(R32(G_N, t), P.rev, v.L, v.RS, r)];
@@ -85,6 +89,7 @@ struct SlotIn {
 };
 
 // Link.cal_sending_flow (link.py:216-370) incl. get_outflow (:199-214) for t' >= free_flow_tau
+template <bool HIST>
 __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, uint32_t& fl) {
   const int RS = v.RS, T1 = v.T1;
   const float nself = x.n_in, nrev = x.n_out, kk = x.k_in, att = x.att_in;
@@ -209,7 +214,7 @@ __device__ __forceinline__ int as_vector(int x) {
 // FUSED: the wave runs inside link_turn_kernel next to the link update of step t-1, which has not stored
 // num_pedestrians[t-1] / density[t-1] yet -- they are recomputed here from [t-2] and the flows of t-1 with the arithmetic of
 // the link update (link.py:133-136), so the parts of that launch do not depend on each other.
-template <bool PR, bool FUSED>
+template <bool PR, bool FUSED, bool HIST>
 __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned block) {
   __shared__ double sP[PEDN_TF_LDS_ROWS * 64];
   __shared__ double sAcc[(PEDN_MAX_DEGREE - 1) * 64];  // coop rows: the turns' sums on their way to wave 0
@@ -512,9 +517,9 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
 }
 
 // stand-alone launch: first step of an episode, or a step that does not follow the previous one
-template <bool PR>
+template <bool PR, bool HIST>
 __global__ __launch_bounds__(256) void turn_frac_kernel(DevView v, int t) {
-  turn_frac_body<PR, false>(v, t, blockIdx.x);
+  turn_frac_body<PR, false, HIST>(v, t, blockIdx.x);
 }
 
 // RegularNode.solve('optimal') (node.py:249-271) for 64 replicas of one node, one LP per lane: dense primal simplex on the
@@ -602,7 +607,7 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // HBM throughput (melbourne: 26.4 us against 28.0).  8: 64 VGPRs with 12 spilled, 4 blocks per CU -- best where it is bound by
 // latency, i.e. with dynamic junctions (delft: 36.6 us against 39.9).  pedn_create picks one per model.
 // LP: the node model is the linear programme of assign_flows_type 'optimal' instead of the classic proportional rule.
-template <bool PR, int WAVES, bool LP = false>
+template <bool PR, int WAVES, bool LP, bool HIST>
 __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   __shared__ double sPS[64 * 64];  // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
   __shared__ double sR[8 * 64];    // receiving flow of each wave's outgoing link
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
       ci_prev = x.ci_out;  // cumulative_inflow[t-1] of the outgoing link
       PH(2, x.n_in + x.k_in + x.att_in + (float)(x.co_in + x.s_prev + x.co_sw + x.ci_out + x.r_prev + x.front_in + x.back_out));
-      s_i = early ? 0.0 : send_flow(v, Pin, lin, tp, r, x, fl);
+      s_i = early ? 0.0 : send_flow<HIST>(v, Pin, lin, tp, r, x, fl);
       PH(3, s_i);
       rowp(v.f64[F_S], R64(F_S, tp), lin, L, RS, r0)[lane] = s_i;  // link.py:268,367
       if (s_i < 0.0) fl |= PEDN_F_NEG_FLOW;
@@ -856,7 +861,7 @@ __device__ __forceinline__ void st2(float* p, size_t i, float a, float b) { *rei
 // each of NS segments of 128 replicas: every history access is a 16-byte (f64) or 8-byte (f32) vector access, i.e. 1 KiB /
 // 512 B contiguous per wave instruction.  NS = 2 halves the number of waves for the same work (twice the loads in flight per
 // wave): used inside link_turn_kernel, where the turning-fraction waves compete for the wave slots.
-template <int NS>
+template <int NS, bool HIST>
 __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
   const int RS = v.RS, L = v.L, Lall = v.Lall, H = RS / (2 * NS);  // lanes per corridor
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)H));
@@ -934,6 +939,7 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
 }
 
 // Same update with per-replica link parameters: one replica per lane (the parameters live in vector registers).
+template <bool HIST>
 __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid) {
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
@@ -964,9 +970,10 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
   if (gb != Pb.width || v.hist) v.f64[F_GATE][at(R64(F_GATE, t), b, L, RS, r)] = gb;
 }
 
-template <int NS>
-__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) { link_body<NS>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
-__global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) { link_pr_body(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
+template <int NS, bool HIST>
+__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) { link_body<NS, HIST>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
+template <bool HIST>
+__global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) { link_pr_body<HIST>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
 
 // ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------
 struct RlView {
@@ -1013,7 +1020,7 @@ __global__ void rl_apply_kernel(DevView v, RlView q) {
 // reference).  FUSED: the block runs inside link_turn_kernel next to the link update of the same step, which has not stored
 // travel time, speed and density of step t yet: they are recomputed for the agent's links with the link update's own
 // arithmetic (speed_calc with the same Philox key), so the parts of that launch stay independent.
-template <bool FUSED>
+template <bool FUSED, bool HIST>
 __device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& q, int t, int accumulate, unsigned block) {
   __shared__ float sT[PEDN_MAX_DEGREE][64], sD[PEDN_MAX_DEGREE][64], sKc[PEDN_MAX_DEGREE][64];
   const int RS = v.RS, L = v.L, Lall = v.Lall;
@@ -1050,7 +1057,7 @@ __device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& 
         tt_l = v.f32[G_TT][at(R32(G_TT, t), l, L, RS, r)];
         tt_r = v.f32[G_TT][at(R32(G_TT, t), P.rev, L, RS, r)];
         spd = q.obs_mode == 5 ? v.f32[G_V][at(R32(G_V, t), l, L, RS, r)] : 0.0f;
-        dens = dens_at(v, P, l, t, r);
+        dens = dens_at<HIST>(v, P, l, t, r);
       } else {  // link.py:133-136 + update_speeds, as in link_body
         const LinkP Pr = v.pr ? lane_params<true>(v, v.lp[P.rev], P.rev, r) : v.lp[P.rev];
         const float na = (float)((double)v.f32[G_N][at(R32(G_N, t - 1), l, L, RS, r)] + (in_ld - out_ld));
@@ -1112,8 +1119,9 @@ __device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& 
   }
 }
 
+template <bool HIST>
 __global__ __launch_bounds__(256) void rl_observe_kernel(DevView v, RlView q, int t, int accumulate) {
-  rl_observe_body<false>(v, q, t, accumulate, blockIdx.x);
+  rl_observe_body<false, HIST>(v, q, t, accumulate, blockIdx.x);
 }
 
 // ONE launch after node_kernel(t) for everything that only reads what node_kernel(t) and earlier launches wrote:
@@ -1123,18 +1131,18 @@ __global__ __launch_bounds__(256) void rl_observe_kernel(DevView v, RlView q, in
 // The parts are independent (the second and third re-derive what the first is about to store), so they run side by side;
 // as separate launches each of them cost 5-9 us, most of it the fixed cost of a launch.
 // (OBS = false: the instantiation ordinary stepping uses carries neither the LDS nor the registers of the third part)
-template <bool PR, bool OBS, int NS>
+template <bool PR, bool OBS, int NS, bool HIST>
 __global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, RlView q, int accumulate) {
   // the turning-fraction workgroups come first in dispatch order: theirs are the long dependent chains of the launch (the
   // heaviest rows lead), the link update behind them is bound by memory throughput and fills the machine around them
   if (blockIdx.x < n_tp_blocks) {
-    turn_frac_body<PR, true>(v, t + 1, blockIdx.x);
+    turn_frac_body<PR, true, HIST>(v, t + 1, blockIdx.x);
   } else if (blockIdx.x < n_tp_blocks + n_link_blocks) {
     const size_t gid = (size_t)(blockIdx.x - n_tp_blocks) * blockDim.x + threadIdx.x;
-    if (PR) link_pr_body(v, t, gid);
-    else link_body<NS>(v, t, gid);
+    if (PR) link_pr_body<HIST>(v, t, gid);
+    else link_body<NS, HIST>(v, t, gid);
   } else if (OBS) {
-    rl_observe_body<true>(v, q, t, accumulate, blockIdx.x - n_link_blocks - n_tp_blocks);
+    rl_observe_body<true, HIST>(v, q, t, accumulate, blockIdx.x - n_link_blocks - n_tp_blocks);
   }
 }
 
