@@ -60,7 +60,6 @@ struct pedn_sim {
   int n_pair = 0, n_up = 0, n_over = 0;
   long step_epoch = 1;  // counts launched steps; h_tf_set_epoch[node] == step_epoch: fractions imposed since the last step
   std::vector<long> h_tf_set_epoch;
-  std::vector<int32_t> dbg_rwords, dbg_gwords, dbg_prow;
   int rows64[7], rows32[6];  // history rows of every field (T+1, or the size of its ring in recent-history mode)
   int last_t = -1;     // last step launched (pedn_get_turning_fractions: which buffer holds a dynamic node's fractions)
   std::vector<void*> allocs;
@@ -311,7 +310,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   v.replica_offset = (uint32_t)replica_offset;
   v.meanfield = rng_mode == PEDN_RNG_MEANFIELD;
   v.n_grp = m->n_grp;
-  if (const char* d = getenv("PEDN_TF_GENERAL")) v.dbg = atoi(d);  // diagnostics: 1 general softmax path, 2 general row-sum path
+  if (const char* d = getenv("PEDN_TF_GENERAL")) v.tf_general = atoi(d);  // diagnostics: 1 general softmax path, 2 general row-sum path
   s->n_nodes = N; s->n_turns = m->n_turns; s->n_demand = m->n_demand; s->n_od = m->n_od; s->n_ent = m->n_ent;
   s->node_turn_ptr.assign(m->node_turn_ptr, m->node_turn_ptr + N + 1);
   s->h_node_slot_ptr.assign(m->node_slot_ptr, m->node_slot_ptr + N + 1);
@@ -525,7 +524,6 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     v.n_multi = n_multi;
     v.n_trow = (int)rows.size();
     s->n_over = n_over;
-    s->dbg_rwords = rwords; s->dbg_gwords = gwords; s->dbg_prow = prow;
     TRY(upload(s, rwords.data(), rwords.size(), &v.trow_words));
     TRY(upload(s, gwords.data(), gwords.size(), &v.tgrp_words));
     TRY(upload(s, prow.data(), prow.size(), &v.pair_row));
@@ -1390,12 +1388,6 @@ int pedn_device_math(int32_t device, int32_t op, int32_t n, const double* a, con
 }
 
 }  // extern "C"
-
-extern "C" int pedn_debug_words(pedn_sim* s, int which, int32_t* out, int n) {
-  const std::vector<int32_t>& w = which == 0 ? s->dbg_rwords : which == 1 ? s->dbg_gwords : s->dbg_prow;
-  for (int i = 0; i < n && i < (int)w.size(); ++i) out[i] = w[i];
-  return (int)w.size();
-}
 
 #ifdef PEDN_PHASE_PROFILE
 // profiling build only (make phase-profile): read (zero = 0) or clear (zero = 1) the 16 phase accumulators of node_kernel

@@ -430,8 +430,8 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
     // the record behind the row's last group belongs to another row: size 0, evaluated on harmless values, nothing stored
     const int na = rdl(gcur, 0), nb = 2 * pi + 1 < n_grp ? rdl(gcur, 32) : 0;
     const int nmax = max(na, nb);
-    if (nmax <= 2 && !(v.dbg & 1)) eval_pair(std::integral_constant<int, 2>{}, gcur, na, nb);
-    else if (nmax <= 3 && !(v.dbg & 1)) eval_pair(std::integral_constant<int, 3>{}, gcur, na, nb);
+    if (nmax <= 2 && !(v.tf_general & 1)) eval_pair(std::integral_constant<int, 2>{}, gcur, na, nb);
+    else if (nmax <= 3 && !(v.tf_general & 1)) eval_pair(std::integral_constant<int, 3>{}, gcur, na, nb);
     else { eval_slow(gcur, 0, na); eval_slow(gcur, 32, nb); }
     gcur = gnext;
   }
@@ -448,7 +448,7 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
     double acc = 0.0;
     if (mode) {
       acc = ppr ? v.turn_tab_r[(size_t)(turn0 + jj) * RS + r] : __hiloint2double(rdl(__double2hiint(ttab), jj), rdl(__double2loint(ttab), jj));
-    } else if (!ppr && !overflow && nq <= 64 && !(v.dbg & 2)) {
+    } else if (!ppr && !overflow && nq <= 64 && !(v.tf_general & 2)) {
       // every probability is the constant 1 or in LDS: four products per pass, no branch in between
       auto lds_prob = [&](int q) -> double {
         const int c = rdl(pcode, q);

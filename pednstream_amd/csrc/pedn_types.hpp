@@ -83,7 +83,7 @@ struct DevView {
   double dt, pf_temp, pf_alpha, pf_beta, pf_omega, pf_eps;
   uint32_t k0, k1, replica_offset;
   int32_t meanfield;
-  int32_t dbg;
+  int32_t tf_general;  // diagnostics (PEDN_TF_GENERAL): 1 the any-size softmax path, 2 the general row-sum path of turn_frac_body
   // history rows: time index t lives in row (t & mask).  Full-record mode: every mask is 0x7fffffff (row = t, T+1 rows, the
   // reference's own footprint).  Recent-history mode (hist = 1): inflow and cumulative_inflow keep all rows (the sending
   // flow looks back an unbounded, data-dependent number of steps into them), the others are rings of mask + 1 rows.
