@@ -486,6 +486,7 @@ CASES.update({
     "rl_nine_opt5g2": lambda: rl_case("rl_nine_opt5g2", "nine_intersections", obs_mode="option5", action_gap=2, env_steps=90, action_seed=3),
     "rl_nine_opt4": lambda: rl_case("rl_nine_opt4", "nine_intersections", obs_mode="option4", env_steps=60, action_seed=4),
     "rl_i45_opt3": lambda: rl_case("rl_i45_opt3", "45_intersections", obs_mode="option3", env_steps=200, action_seed=5),
+    "rl_i45_episode": lambda: rl_case("rl_i45_episode", "45_intersections", obs_mode="option3", env_steps=698, action_seed=15),
     "rl_corridor_opt1": lambda: rl_case("rl_corridor_opt1", "long_corridor", obs_mode="option1", env_steps=200, action_seed=6),
 })
 CASES.update({   # the remaining scenario directories of the reference's data/ (RL datasets with controller nodes)
@@ -502,6 +503,8 @@ CASES.update({   # the remaining scenario directories of the reference's data/ (
 })
 CASES.update({   # full-horizon pins of the two headline networks (every step, every link, through per-step digests)
     "melbourne_full": lambda: digest_case("melbourne_full", "melbourne", seed=2, replica=3),
+    "i45_full": lambda: digest_case("i45_full", "45_intersections", seed=4, replica=2),
+    "two_coordinators_full": lambda: digest_case("two_coordinators_full", "two_coordinators", seed=5, replica=4),
     "delft_full": lambda: digest_case("delft_full", "delft", seed=1, replica=5),
     # melbourne under heavy demand: the release binomials, the diffusion look-backs and the congested branch fire
     "melbourne_heavy_a": lambda: digest_case("melbourne_heavy_a", "melbourne", seed=2, replica=7,

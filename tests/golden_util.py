@@ -129,7 +129,7 @@ def compare_fields(get_field, g: Golden, n_links, last, f32_exact=True):
     return problems
 
 
-DIGEST_CASES = ["melbourne_full", "melbourne_heavy_a", "melbourne_heavy_b", "delft_full"]
+DIGEST_CASES = ["melbourne_full", "melbourne_heavy_a", "melbourne_heavy_b", "delft_full", "i45_full", "two_coordinators_full"]
 
 
 def step_digests(arr):

@@ -9,7 +9,7 @@ from pednstream_amd.rl_env import AgentManager
 from rl_oracle import RlOracle
 
 RL_CASES = ["rl_nine_opt3", "rl_nine_opt2n", "rl_nine_opt5g2", "rl_nine_opt4", "rl_i45_opt3", "rl_corridor_opt1", "rl_butterfly_opt3",
-            "rl_one_intersection_opt5", "rl_nine_partial", "rl_corridor_partial"]
+            "rl_one_intersection_opt5", "rl_nine_partial", "rl_corridor_partial", "rl_i45_episode"]
 
 
 def agent_spec(net):
