@@ -8,11 +8,6 @@ import time
 
 import numpy as np
 
-try:
-    import torch  # noqa: F401  -- before the engine library is loaded: one HIP runtime per process (see VecPedNetEnv.step_device)
-except ImportError:
-    torch = None
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pednstream_amd.rl_env import VecPedNetEnv  # noqa: E402
 
@@ -35,8 +30,10 @@ def main():
           f"mean return of the first agent {ret.mean():.1f}")
 
     # the same rollout with the policy on the GPU: actions are sampled by torch on the device, observations and rewards are
-    # torch views of the engine's buffers -- nothing crosses PCIe
-    if torch is None:
+    # torch views of the engine's buffers -- nothing crosses PCIe (torch may be imported after the engine: one HIP runtime)
+    try:
+        import torch
+    except ImportError:
         env.close()
         return
     env.reset(options={"randomize": True, "mode": "vectorised"}, seed=2)

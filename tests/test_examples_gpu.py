@@ -1,0 +1,20 @@
+"""The example scripts run end to end on the GPU box (drop-in use of the reference's API through compat)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("script,args,expect", [
+    ("six_node.py", [], "sum of cumulative inflow at t=499"),
+    ("delft_exp.py", ["4"], "busiest link"),
+    ("vec_env_rollout.py", ["64", "40"], "agents"),
+])
+def test_example_runs(script, args, expect, tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert expect in out.stdout, out.stdout[-1000:]
