@@ -33,6 +33,9 @@ struct pedn_sim {
   int node_waves = 8;  // register budget of node_kernel, see pedn_create
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
   int link_ns = 1;     // segments of 128 replicas per lane of the link update (launch_step); PEDN_LINK_NS=1|2
+  size_t node_lds = 0;    // dynamic LDS bytes of node_kernel
+  int second_launch = 0;  // launch_step: a launch followed node_kernel
+  int fuse_link = 0;   // node_kernel<FUSE> also does the link update (the later of a corridor's two end waves): no link launch
   int fuse_tp = 0;     // the link update and the next step's turn probabilities share one launch (launch_step)
   int tp_ran = 0;      // launch_step launched the stand-alone turn_frac_kernel (pedn_profile_step)
   int tp_ready = -1;   // step whose turning fractions are in tfd[step & 1] (written by link_turn_kernel of the step before), -1: none
@@ -142,6 +145,7 @@ static int reset_state(pedn_sim* s) {
   DevView& v = s->v;
   for (int f = 0; f < 4; ++f) HIP_TRY(s, hipMemsetAsync(v.f64[f], 0, (size_t)s->rows64[f] * v.Lall * v.RS * sizeof(double), s->stream));
   HIP_TRY(s, hipMemsetAsync(v.flags, 0, (size_t)v.RS * sizeof(uint32_t), s->stream));
+  HIP_TRY(s, hipMemsetAsync(v.arrive, 0, (size_t)std::max(v.n_pairs_corr, 1) * (v.RS / 64) * sizeof(int32_t), s->stream));
   if (v.L > 0) {
     int max_rows = 0;  // over the fields init_state_kernel fills (all of them have L columns)
     for (int f = 4; f < 7; ++f) max_rows = std::max(max_rows, s->rows64[f]);
@@ -345,7 +349,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     P.length = m->link_length[l]; P.width = m->link_width[l]; P.vf = m->link_vf[l]; P.kc = m->link_kc[l]; P.kj = m->link_kj[l];
     P.gamma = m->link_gamma[l]; P.act = m->link_act[l]; P.bi = m->link_bi[l]; P.noise = m->link_noise[l];
     P.tt0 = m->link_tt0[l]; P.rev = m->link_rev[l]; P.sep = m->link_sep[l]; P.fd = m->link_fd[l];
-    P.tau_sw = m->link_tau_sw[l]; P.fft = m->link_fft[l]; P.pad[0] = P.pad[1] = 0;
+    P.tau_sw = m->link_tau_sw[l]; P.fft = m->link_fft[l]; P.pad = 0;
+    P.derive();
   }
   TRY(upload(s, lp.data(), lp.size(), &v.lp));
   TRY(upload(s, m->node_kind, N, &v.node_kind));
@@ -532,6 +537,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     v.n_turns = m->n_turns;
   }
   TRY(upload(s, m->od_w, (size_t)m->n_od * v.T1, &v.od_w));
+  std::vector<int> corr_of;  // link -> corridor
   {  // corridors: one lane of link_kernel updates both directions
     std::vector<CorrRec> cr;
     for (int l = 0; l < L; ++l)
@@ -542,6 +548,10 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       }
     v.n_pairs_corr = (int)cr.size();
     TRY(upload(s, cr.data(), cr.size(), &v.corr_rec));
+    corr_of.assign((size_t)std::max(L, 1), -1);
+    for (size_t p = 0; p < cr.size(); ++p) corr_of[cr[p].a] = corr_of[cr[p].b] = (int)p;
+    TRY(dalloc(s, std::max<size_t>(cr.size(), 1) * (size_t)(v.RS / 64), &v.arrive));
+    HIP_TRY(s, hipMemset(v.arrive, 0, std::max<size_t>(cr.size(), 1) * (size_t)(v.RS / 64) * sizeof(int32_t)));
   }
   {  // bin nodes into blocks of 8 waves: first-fit over the nodes ordered by (expected load, slot count) decreasing, so that
     // every block is full regardless of node degree.  The 8 waves of a block meet at two barriers, so a block lasts as long
@@ -583,12 +593,23 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
           R.lout = m->slot_out_link[m->node_slot_ptr[n] + k];
           R.turn0 = m->node_turn_ptr[n];
           R.demand_row = m->node_demand_row[n];
-          if (R.lin < L) { R.Pin = lp[R.lin]; R.Pout = lp[R.lout]; }
+          R.corr = -1;
+          if (R.lin < L) { R.Pin = lp[R.lin]; R.Pout = lp[R.lout]; R.corr = corr_of[R.lout]; }
         }
         base += d * d;  // <= 64 tiles because sum(d) <= 8
       }
     }
     s->n_blocks = (int)bins.size();
+    {  // LDS of node_kernel: 8 (LP: 16) rows of 64 doubles + the m*m tiles of the fullest block
+      int tiles = 1;
+      for (const auto& bin : bins) {
+        int t2 = 0;
+        for (int n : bin) t2 += deg(n) * deg(n);
+        tiles = std::max(tiles, t2);
+      }
+      s->node_lds = (size_t)((m->node_model == PEDN_NODE_OPTIMAL ? 16 : 8) + tiles) * 64 * sizeof(double);
+      if (const char* f = getenv("PEDN_NODE_LDS_FULL")) if (atoi(f)) s->node_lds = (size_t)(16 + 64) * 64 * sizeof(double);
+    }
     // register budget of node_kernel: compiled for 8 waves per SIMD (64 VGPRs, a few SGPR spills) or for 6 (measured: delft 32.6
     // against 35.0 us, melbourne 25.8 against 27.1); PEDN_NODE_WAVES=6|8 overrides
     s->node_waves = 8;
@@ -600,6 +621,11 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
     if (const char* f = getenv("PEDN_LINK_NS")) s->link_ns = atoi(f) == 2 ? 2 : 1;
     for (SlotRec& R : rec) { R.act = -1; R.lp = -1; }
+    // PEDN_FUSE_LINK=1: node_kernel<FUSE> does the link update too (the later of a corridor's two end waves) and the link launch
+    // goes away.  Parity-green, but not faster (the update's arithmetic and its extra memory round trip land
+    // on waves that hold a full CU's wave slots), so it is off unless asked for.
+    s->fuse_link = 0;
+    if (const char* f = getenv("PEDN_FUSE_LINK")) s->fuse_link = atoi(f) != 0 && m->node_model != PEDN_NODE_OPTIMAL && s->node_waves == 8;
     s->node_lp = m->node_model == PEDN_NODE_OPTIMAL;
     if (s->node_lp) {  // tableau workspace: one per (regular node, replica group), sized for the largest such node
       int n_lp = 0, max_m = 0;
@@ -924,6 +950,8 @@ static node_kernel_fn node_kernel_for(const pedn_sim* s) {
   const bool h = s->v.hist != 0;  // recent-history mode: the instantiations that mask the history rows
   if (s->node_lp) return s->v.pr ? (h ? node_kernel<true, 8, true, true> : node_kernel<true, 8, true, false>)
                                  : (h ? node_kernel<false, 8, true, true> : node_kernel<false, 8, true, false>);
+  if (s->fuse_link) return s->v.pr ? (h ? node_kernel<true, 8, false, true, true> : node_kernel<true, 8, false, false, true>)
+                                   : (h ? node_kernel<false, 8, false, true, true> : node_kernel<false, 8, false, false, true>);
   if (s->v.pr) return s->node_waves == 8 ? (h ? node_kernel<true, 8, false, true> : node_kernel<true, 8, false, false>)
                                          : (h ? node_kernel<true, 6, false, true> : node_kernel<true, 6, false, false>);
   return s->node_waves == 8 ? (h ? node_kernel<false, 8, false, true> : node_kernel<false, 8, false, false>)
@@ -952,10 +980,12 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     else { if (v.hist) launch(turn_frac_kernel<false, true>, dim3(nb), dim3(256), 0, v, t); else launch(turn_frac_kernel<false, false>, dim3(nb), dim3(256), 0, v, t); }
     s->tp_ran = 1;
   }
-  launch(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), 2, vn, t);
+  if (ev) hipExtLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, s->stream, ev[2], ev[3], 0, vn, t);
+  else hipLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, s->stream, vn, t);
   // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
   const int ns = (!v.pr && s->link_ns == 2 && v.RS % 256 == 0) ? 2 : 1;
-  const unsigned nlb = v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / (2 * ns)) + 255) / 256) : 0u;
+  const unsigned nlb = v.n_pairs_corr > 0 && !s->fuse_link ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / (2 * ns)) + 255) / 256) : 0u;
+  s->second_launch = 1;
   if (fused || obs_fused) {
     const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;
     const unsigned nob = obs_fused ? (unsigned)s->rl.n_agents * rgroups : 0u;  // one block per (agent, 64 replicas)
@@ -977,11 +1007,12 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     }
 #undef PEDN_LT
     if (fused) s->tp_ready = t + 1;
-  } else if (v.n_pairs_corr > 0) {
+  } else if (nlb > 0) {
     if (v.pr) { if (v.hist) launch(link_kernel_pr<true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel_pr<false>, dim3(nlb), dim3(256), 4, v, t); }
     else if (ns == 2) { if (v.hist) launch(link_kernel<2, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel<2, false>, dim3(nlb), dim3(256), 4, v, t); }
     else { if (v.hist) launch(link_kernel<1, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel<1, false>, dim3(nlb), dim3(256), 4, v, t); }
   }
+  else s->second_launch = 0;
   if (observed) *observed = obs_fused;
   s->last_t = t;
   ++s->step_epoch;
@@ -1001,7 +1032,6 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   if (!s || !ms) return fail(s, PEDN_E_ARG, "null argument");
   if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
-  DevView& v = s->v;
   // hipExtLaunchKernelGGL start/stop events carry the dispatch's own begin/end timestamps (what rocprofv3 reports),
   // not the enqueue-to-completion interval an ordinary hipEventRecord bracket would measure.
   hipEvent_t ev[6];
@@ -1013,7 +1043,7 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   ms[0] = ms[1] = ms[2] = 0.0f;
   if (s->tp_ran) HIP_TRY(s, hipEventElapsedTime(&ms[0], ev[0], ev[1]));  // stand-alone turn probabilities (normally fused into [2])
   HIP_TRY(s, hipEventElapsedTime(&ms[1], ev[2], ev[3]));
-  if (v.n_pairs_corr > 0 || v.n_trow > 0) HIP_TRY(s, hipEventElapsedTime(&ms[2], ev[4], ev[5]));
+  if (s->second_launch) HIP_TRY(s, hipEventElapsedTime(&ms[2], ev[4], ev[5]));
   for (int i = 0; i < 6; ++i) hipEventDestroy(ev[i]);
   return PEDN_OK;
 }

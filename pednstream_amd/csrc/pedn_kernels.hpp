@@ -60,6 +60,7 @@ __device__ __forceinline__ LinkP lane_params(const DevView& v, const LinkP& P, i
     const size_t i = (size_t)l * v.RS + r;
     Q.kc = v.kc_r[i]; Q.kj = v.kj_r[i]; Q.vf = v.vf_r[i];
     Q.fft = v.fft_r[i]; Q.tau_sw = v.tausw_r[i]; Q.tt0 = v.tt0_r[i];
+    Q.derive();
   }
   return Q;
 }
@@ -75,7 +76,7 @@ template <bool HIST>
 __device__ __forceinline__ float dens_at(const DevView& v, const LinkP& P, int l, int t, int r) {
   if (P.sep) return v.f32[G_K][at(R32(G_K, t), l, v.L, v.RS, r)];
   float n = v.f32[G_N][at(R32(G_N, t), l, v.L, v.RS, r)] + v.f32[G_N][at(R32(G_N, t), P.rev, v.L, v.RS, r)];
-  return n / (float)(P.length * P.width);
+  return n / P.area32;
 }
 
 // Everything of step t' = t-1 a slot wave needs from HBM whose address does not depend on data: fetched as ONE batch of
@@ -93,13 +94,12 @@ template <bool HIST>
 __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, uint32_t& fl) {
   const int RS = v.RS, T1 = v.T1;
   const float nself = x.n_in, nrev = x.n_out, kk = x.k_in, att = x.att_in;
-  double aw = P.sep ? x.sepw_in : P.width;
-  float dens = P.sep ? kk : (nself + nrev) / (float)(P.length * aw);
+  float dens = P.sep ? kk : (nself + nrev) / P.area32;
   int tau = __float2int_rn(att / (float)v.dt);  // link.py:260
   if (tau <= 0) fl |= PEDN_F_SAME_STEP;
   int idx = tp + 1 - tau;
   if (idx < 0) idx = 0;
-  float cf = clip01((kk - (float)P.kc) / (float)(P.kj - P.kc));  // link.py:282
+  float cf = clip01((kk - P.kc32) / P.dk32);  // link.py:282
   double ff = v.f64[F_CI][at(R64(F_CI, idx), l, v.Lall, RS, r)] - x.co_in;  // the one data-dependent look-back of the common path
   if (!(ff > 0.0)) ff = 0.0;
   double bnd = (double)(cf * nself) + (double)(1.0f - cf) * ff;  // link.py:284-288
@@ -108,11 +108,11 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
   double orig = s;
   RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)tp, 0u};
   if (s > 0.0) {
-    float rf = clip01(dens / (float)P.kj);                          // link.py:315
+    float rf = clip01(dens / P.kj32);                          // link.py:315
     float p = 0.7f + (float)(0.85 - 0.7) * pedn_powf(rf, 0.8f);     // link.py:317
     bool diffusion_used = false;
-    if (dens <= (float)P.kc) {  // link.py:323
-      float F = 1.0f / (1.0f + (float)P.gamma * att);
+    if (dens <= P.kc32) {  // link.py:323
+      float F = 1.0f / (1.0f + P.gamma32 * att);
       float G = 1.0f - F;
       const double* in = v.f64[F_IN];
       double i0 = in[at(wrap_idx(tp - tau, T1, fl), l, v.Lall, RS, r)], i1 = in[at(wrap_idx(tp - tau - 1, T1, fl), l, v.Lall, RS, r)];
@@ -147,8 +147,7 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
 // Link/Separator.cal_receiving_flow[_with_reverse] (link.py:372-416,480-512); the reverse link is the slot's incoming link
 __device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, double s_rev, uint32_t& fl) {
   const float nrev = x.n_in;
-  double aw = P.sep ? x.sepw_out : P.width;
-  double kjA = P.kj * (P.length * aw);
+  double kjA = P.sep ? P.kj * (P.length * x.sepw_out) : P.kjA;
   int tsw = P.tau_sw;
   double b;
   if (P.sep) {
@@ -607,11 +606,23 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // HBM throughput (melbourne: 26.4 us against 28.0).  8: 64 VGPRs with 12 spilled, 4 blocks per CU -- best where it is bound by
 // latency, i.e. with dynamic junctions (delft: 36.6 us against 39.9).  pedn_create picks one per model.
 // LP: the node model is the linear programme of assign_flows_type 'optimal' instead of the classic proportional rule.
-template <bool PR, int WAVES, bool LP, bool HIST>
+// FUSE: the link update of t happens in this launch too.  A corridor's state needs inflow[t] / outflow[t] of both directions,
+// i.e. the results of the two slot waves at its two ends, which run in different workgroups: each wave publishes its two flows
+// write-through (sc1), waits for its stores, then adds to the corridor's arrival counter (agent scope); the wave whose add comes
+// second loads the other wave's two flows (sc1 loads, they bypass this CU's L1) and updates both directions.  No wave waits for
+// another.  The counters are never reset inside a step: every launch adds exactly two, the parity tells first from second.
+template <bool HIST>
+__device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& Pa, const LinkP& Pb, int a, int b, int t, int r,
+                                                double da, double db, float pa, float pb);
+
+template <bool PR, int WAVES, bool LP, bool HIST, bool FUSE = false>
 __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
-  __shared__ double sPS[64 * 64];  // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
-  __shared__ double sR[8 * 64];    // receiving flow of each wave's outgoing link
-  __shared__ double sS[LP ? 8 * 64 : 1];  // LP: sending flow of each wave's incoming link
+  // dynamic LDS, sized by the host for the fullest block (pedn_create: node_lds): a block of nodes of degree 3..4 needs 24 of
+  // the 64 tiles a single degree-8 node would, and LDS a block does not hold lets the CU start the next block earlier
+  extern __shared__ double pedn_lds[];
+  double* const sR = pedn_lds;                          // [8][64] receiving flow of each wave's outgoing link
+  double* const sS = pedn_lds + 8 * 64;                 // [8][64] LP only: sending flow of each wave's incoming link
+  double* const sPS = pedn_lds + (LP ? 16 : 8) * 64;    // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
   const int RS = v.RS, L = v.L, Lall = v.Lall;
@@ -626,11 +637,13 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
 #endif
   const SlotRec& W = v.slot_rec[(size_t)blockIdx.y * 8 + wave];  // wave-uniform: scalar loads
   const int node = W.node, slot = W.slot, base = W.base, m = W.m;
+  const int corr = FUSE ? W.corr : -1;  // read here: behind the hand-off's memory clobber it would be a vector load in front of the add
   const bool active = node >= 0;
   PH(1, lane + node);
   uint32_t fl = 0;
   double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0, co_prev = 0.0, ci_prev = 0.0;
   int lin = 0, lout = 0, kind = 0;
+  float np_in = 0.0f, np_out = 0.0f;  // FUSE: num_pedestrians[t-1] of the slot's two links, kept for their update
   double tfr[PEDN_MAX_DEGREE - 1];
 
   if (active) {
@@ -699,7 +712,8 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
         for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
           if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
       }
-      if (!Pin.sep) x.k_in = x.n_in / (float)(Pin.length * Pin.width);
+      if (!Pin.sep) x.k_in = x.n_in / Pin.area32;
+      if (FUSE) { np_in = x.n_in; np_out = x.n_out; }
       co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
       ci_prev = x.ci_out;  // cumulative_inflow[t-1] of the outgoing link
       PH(2, x.n_in + x.k_in + x.att_in + (float)(x.co_in + x.s_prev + x.co_sw + x.ci_out + x.r_prev + x.front_in + x.back_out));
@@ -787,11 +801,29 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       if (qo < 0.0 || qi < 0.0) fl |= PEDN_F_NEG_FLOW;
     }
     // Node.update_links (node.py:146-162; link.py:19-25)
-    rowp(v.f64[F_OUT], R64(F_OUT, t), lin, Lall, RS, r0)[lane] = qo;
+    double* const p_out = rowp(v.f64[F_OUT], R64(F_OUT, t), lin, Lall, RS, r0) + lane;
+    double* const p_in = rowp(v.f64[F_IN], R64(F_IN, t), lout, Lall, RS, r0) + lane;
     rowp(v.f64[F_CO], R64(F_CO, t), lin, Lall, RS, r0)[lane] = co_prev + qo;
-    rowp(v.f64[F_IN], R64(F_IN, t), lout, Lall, RS, r0)[lane] = qi;
     rowp(v.f64[F_CI], R64(F_CI, t), lout, Lall, RS, r0)[lane] = ci_prev + qi;
     if (fl) atomicOr(&v.flags[r], fl);
+    if (FUSE && lin < L) {
+      __hip_atomic_store(p_out, qo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
+      __hip_atomic_store(p_in, qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's flows have left the chip's caches before it signals
+      int arrived = 0;
+      if (lane == 0) arrived = __hip_atomic_fetch_add(&v.arrive[(size_t)corr * gridDim.x + blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      arrived = __builtin_amdgcn_readfirstlane(arrived);
+      if (arrived & 1) {  // the other end of the corridor has published: Network.update_link_states for both directions
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double in_lin = __hip_atomic_load(rowp(v.f64[F_IN], R64(F_IN, t), lin, Lall, RS, r0) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double out_lout = __hip_atomic_load(rowp(v.f64[F_OUT], R64(F_OUT, t), lout, Lall, RS, r0) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const LinkP Pa = lane_params<PR>(v, W.Pout, lout, r), Pb = lane_params<PR>(v, W.Pin, lin, r);
+        link_update_one<HIST>(v, Pa, Pb, lout, lin, t, r, qi - out_lout, in_lin - qo, np_out, np_in);
+      }
+    } else {
+      *p_out = qo;
+      *p_in = qi;
+    }
   }
 #ifdef PEDN_PHASE_PROFILE
   PH(9, qo + qi);
@@ -915,7 +947,7 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
       sa[j] = speed_calc(v, Pa, a, t, r + j, ka[j], kb[j], rsav[j], oav[j]);
       sb[j] = speed_calc(v, Pb, b, t, r + j, kb[j], ka[j], rsbv[j], obv[j]);
     }
-    // ---- stores
+    // ---- stores: all at the end (issued as their values appear, between the two speed computations, the launch is 0.5 us slower)
     st2(v.f32[G_N], at(R32(G_N, t), a, L, RS, r), na[0], na[1]);
     st2(v.f32[G_N], at(R32(G_N, t), b, L, RS, r), nb[0], nb[1]);
     st2(v.f32[G_K], at(R32(G_K, t), a, L, RS, r), ka[0], ka[1]);
@@ -938,20 +970,14 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
   }
 }
 
-// Same update with per-replica link parameters: one replica per lane (the parameters live in vector registers).
+// The link update of both directions of one corridor for ONE replica, given inflow[t] - outflow[t] (da, db) and
+// num_pedestrians[t-1] (pa, pb) of the two directions; everything else it needs it loads itself.
 template <bool HIST>
-__device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid) {
-  const int RS = v.RS, L = v.L, Lall = v.Lall;
-  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
-  const int r = (int)(gid % (size_t)RS);
-  if (p >= v.n_pairs_corr) return;
-  const CorrRec& C = v.corr_rec[p];
-  const int a = C.a, b = C.b;
-  const LinkP Pa = lane_params<true>(v, C.Pa, a, r), Pb = lane_params<true>(v, C.Pb, b, r);
+__device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& Pa, const LinkP& Pb, int a, int b, int t, int r,
+                                                double da, double db, float pa, float pb) {
+  const int RS = v.RS, L = v.L;
   const bool win = t >= v.W;
-  const double da = v.f64[F_IN][at(R64(F_IN, t), a, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), a, Lall, RS, r)];
-  const double db = v.f64[F_IN][at(R64(F_IN, t), b, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), b, Lall, RS, r)];
-  const float na = (float)((double)v.f32[G_N][at(R32(G_N, t - 1), a, L, RS, r)] + da), nb = (float)((double)v.f32[G_N][at(R32(G_N, t - 1), b, L, RS, r)] + db);
+  const float na = (float)((double)pa + da), nb = (float)((double)pb + db);
   const double wa = Pa.sep ? v.sepw[(size_t)a * RS + r] : Pa.width, wb = Pb.sep ? v.sepw[(size_t)b * RS + r] : Pb.width;
   const float ka = (Pa.sep && v.sepnp[(size_t)a * RS + r] != 0.0) ? (float)((double)na / (Pa.length * wa)) : na / (float)(Pa.length * wa);
   const float kb = (Pb.sep && v.sepnp[(size_t)b * RS + r] != 0.0) ? (float)((double)nb / (Pb.length * wb)) : nb / (float)(Pb.length * wb);
@@ -968,6 +994,21 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
   v.rsum[(size_t)a * RS + r] = sa.rs; v.rsum[(size_t)b * RS + r] = sb.rs;
   if (ga != Pa.width || v.hist) v.f64[F_GATE][at(R64(F_GATE, t), a, L, RS, r)] = ga;
   if (gb != Pb.width || v.hist) v.f64[F_GATE][at(R64(F_GATE, t), b, L, RS, r)] = gb;
+}
+
+// Same update with per-replica link parameters: one replica per lane (the parameters live in vector registers).
+template <bool HIST>
+__device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid) {
+  const int RS = v.RS, L = v.L, Lall = v.Lall;
+  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
+  const int r = (int)(gid % (size_t)RS);
+  if (p >= v.n_pairs_corr) return;
+  const CorrRec& C = v.corr_rec[p];
+  const int a = C.a, b = C.b;
+  const LinkP Pa = lane_params<true>(v, C.Pa, a, r), Pb = lane_params<true>(v, C.Pb, b, r);
+  const double da = v.f64[F_IN][at(R64(F_IN, t), a, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), a, Lall, RS, r)];
+  const double db = v.f64[F_IN][at(R64(F_IN, t), b, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), b, Lall, RS, r)];
+  link_update_one<HIST>(v, Pa, Pb, a, b, t, r, da, db, v.f32[G_N][at(R32(G_N, t - 1), a, L, RS, r)], v.f32[G_N][at(R32(G_N, t - 1), b, L, RS, r)]);
 }
 
 template <int NS, bool HIST>

@@ -12,9 +12,16 @@ enum { G_TT = 0, G_ATT, G_N, G_K, G_V, G_LF };
 
 struct LinkP {  // static per-link parameters, wave-uniform on the device
   double length, width, vf, kc, kj, gamma, act, bi, noise;
+  double kjA;                                  // kj * (length * width): jam capacity of an unseparated link (link.py:386)
   float tt0;
+  float kc32, kj32, dk32, area32, gamma32;     // (float)kc, (float)kj, (float)(kj - kc), (float)(length * width), (float)gamma:
+                                               // the float32 casts the formulas take of wave-uniform doubles, made once on the host
   int32_t rev, sep, fd, tau_sw, fft;
-  int32_t pad[2];
+  int32_t pad;
+  __host__ __device__ void derive() {
+    kjA = kj * (length * width);
+    kc32 = (float)kc; kj32 = (float)kj; dk32 = (float)(kj - kc); area32 = (float)(length * width); gamma32 = (float)gamma;
+  }
 };
 
 struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything static it needs, fetched by ONE scalar load burst
@@ -22,7 +29,8 @@ struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything sta
   // 2 turn_tab[t] / turn_tab_r (every product constant: replica-independent, tabulated and renormalised on the host)
   // act: action slot of the batched RL step that sets this slot's gate (back gate of lout = front gate of lin), -1 none
   // lp: index of the node among those that solve the node LP (assign_flows_type 'optimal'), on the node's slot 0, else -1
-  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, act, lp;
+  // corr: index of the corridor (lin, lout) in corr_rec -- its arrival counter in the fused node + link launch -- or -1
+  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, act, lp, corr, pad;
   LinkP Pin, Pout;  // parameters of the incoming / outgoing link of the slot (unused for a virtual pair)
 };
 
@@ -73,6 +81,7 @@ struct DevView {
   const LinkP* lp;
   const SlotRec* slot_rec;
   const CorrRec* corr_rec;
+  int32_t* arrive;  // [n_pairs_corr][RS / 64] arrivals of a corridor's two end waves (fused node + link launch; two per step)
   const int32_t *node_kind, *node_slot_ptr, *node_turn_ptr, *node_demand_row, *node_dyn, *slot_in, *slot_out;
   const int32_t* pair_row;      // [n_pair] where the product's P(down | up, od) is: -1 the constant 1 (single-entry group), else as word 9 + e of a group record
   const int32_t* trow_words;    // [n_trow][PEDN_TROW_WORDS] rows of dynamic nodes, heaviest first

@@ -182,8 +182,9 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
 
-    def history(fuse, waves, stepwise, general="0", lds_limit="64"):
+    def history(fuse, waves, stepwise, general="0", lds_limit="64", fuse_link="0"):
         monkeypatch.setenv("PEDN_FUSE_TP", fuse)
+        monkeypatch.setenv("PEDN_FUSE_LINK", fuse_link)       # 1: the link update inside node_kernel (the later of a corridor's two end waves)
         monkeypatch.setenv("PEDN_NODE_WAVES", waves)
         monkeypatch.setenv("PEDN_TF_GENERAL", general)        # 3: softmax groups and row sums through their general (any-size) paths
         monkeypatch.setenv("PEDN_TF_LDS_LIMIT", lds_limit)    # 1: all but one probability of a row overflow from LDS into HBM
@@ -207,7 +208,7 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
 
     ref = history("0", "6", False)
     for variant in (("1", "6", False), ("0", "8", False), ("1", "8", True), ("1", "8", False, "3", "64"), ("0", "8", False, "1", "1"),
-                    ("1", "8", True, "0", "0")):
+                    ("1", "8", True, "0", "0"), ("1", "8", True, "0", "64", "1"), ("0", "8", False, "0", "64", "1")):
         got = history(*variant)
         for f in ALL_FIELDS:
             assert np.array_equal(ref[f], got[f]), (variant, f)
@@ -369,8 +370,8 @@ def test_per_replica_widths_and_turning_fractions_via_replica_scope():
     net.close()
 
 
-@pytest.mark.parametrize("fuse_tp,general,lds_limit", [("1", "0", "64"), ("0", "0", "64"), ("1", "3", "1")])
-def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, monkeypatch):
+@pytest.mark.parametrize("fuse_tp,general,lds_limit,fuse_link", [("1", "0", "64", "0"), ("0", "0", "64", "0"), ("1", "3", "1", "0"), ("1", "0", "64", "1")])
+def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, fuse_link, monkeypatch):
     """(with the next step's turn probabilities fused into the link update launch, and launched on their own: nine of the
     networks put separator links into softmax groups, whose density the fused launch re-derives)
     40 random scenarios (random trees + chords, all three fundamental diagrams, separators, controllers, activity,
@@ -384,6 +385,7 @@ def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, 
     monkeypatch.setenv("PEDN_FUSE_TP", fuse_tp)
     monkeypatch.setenv("PEDN_TF_GENERAL", general)
     monkeypatch.setenv("PEDN_TF_LDS_LIMIT", lds_limit)
+    monkeypatch.setenv("PEDN_FUSE_LINK", fuse_link)
     ran = 0
     for seed in range(3000, 3040):
         adj, params, origins, dests = random_case(seed)
