@@ -17,7 +17,7 @@ export TMPDIR=/tmp
 
 profile() {  # $1 = suffix ("" or "_delft"), rest = bench arguments
   local SUF=$1; shift
-  rm -rf $O/kt$SUF $O/pf$SUF $O/pw$SUF $O/sq1$SUF $O/sq2$SUF
+  rm -rf $O/kt$SUF $O/pf$SUF $O/pw$SUF $O/sq1$SUF $O/sq2$SUF $O/sq3$SUF $O/sq4$SUF
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt$SUF -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra > $O/kt$SUF.log 2>&1
   echo "kernel trace$SUF done"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf$SUF -- python3 $R/bench.py "$@" --steps 48 --warmup 20 --no-cpu-baseline --no-extra > $O/pf$SUF.log 2>&1
@@ -25,6 +25,9 @@ profile() {  # $1 = suffix ("" or "_delft"), rest = bench arguments
   echo "FETCH/WRITE$SUF done"
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/sq1$SUF -- python3 $R/bench.py "$@" --steps 48 --warmup 20 --no-cpu-baseline --no-extra > $O/sq1$SUF.log 2>&1 || echo "SQ pass 1 failed (see sq1$SUF.log)"
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/sq2$SUF -- python3 $R/bench.py "$@" --steps 48 --warmup 20 --no-cpu-baseline --no-extra > $O/sq2$SUF.log 2>&1 || echo "SQ pass 2 failed (see sq2$SUF.log)"
+  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/sq3$SUF -- python3 $R/bench.py "$@" --steps 48 --warmup 20 --no-cpu-baseline --no-extra > $O/sq3$SUF.log 2>&1 || echo "SQ pass 3 failed (see sq3$SUF.log)"
+  rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/sq4$SUF -- python3 $R/bench.py "$@" --steps 48 --warmup 20 --no-cpu-baseline --no-extra > $O/sq4$SUF.log 2>&1 || echo "SQ pass 4 failed (see sq4$SUF.log)"
+  (cd $R && python3 tools/summarize_busy.py $O/sq3$SUF $O/sq4$SUF > $P/$TAG${SUF}_unit_busy.json) || true
   echo "SQ$SUF done"
   (cd $R && python3 tools/summarize_profiles.py $TAG$SUF $O/kt$SUF $O/pf$SUF $O/pw$SUF $O/cf $O/cw 20)
   (cd $R && python3 tools/summarize_sq.py $O/sq1$SUF $O/sq2$SUF --skip 20 > $P/$TAG${SUF}_sq_counters.json) || true
@@ -48,7 +51,7 @@ for r, lab in zip(rows, labels):
     us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     print(f"  {lab:32s} {us:9.1f} us  {1.5 * 2**30 / us / 1e6:7.2f} TB/s")
 PY
-  rm -rf $O/kt* $O/pf* $O/pw* $O/sq1* $O/sq2* $O/cf $O/cw $O/sc      # the raw traces are large; the summaries above are what is kept
+  rm -rf $O/kt* $O/pf* $O/pw* $O/sq1* $O/sq2* $O/sq3* $O/sq4* $O/cf $O/cw $O/sc      # the raw traces are large; the summaries above are what is kept
 fi
 cd $R
 if [ "$PART" = all ] || [ "$PART" = bench ]; then
@@ -65,6 +68,9 @@ if [ "$PART" = all ] || [ "$PART" = extras ]; then
   python3 tools/turn_phase_profile.py delft | sed 's/^== /== (inside link_turn_kernel) /' >> $P/${TAG}_phase_profile.txt 2>> $O/bench.err
   python3 tools/dropin_time.py > $P/${TAG}_dropin_time.txt 2>> $O/bench.err
   /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/xstream tools/xstream_bench.hip 2> /dev/null && timeout -k 5 60 /tmp/xstream > $P/${TAG}_cross_stream_dependency.txt 2>&1 || true
+  /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/valu_rates tools/valu_rates.hip 2> /dev/null && timeout -k 5 60 /tmp/valu_rates > $P/${TAG}_valu_rates.txt 2>&1 || true
+  # the link update inside node_kernel ("last arriver") against the two-launch plan, alternately on this box
+  { for i in 1 2; do for f in 0 1; do PEDN_FUSE_LINK=$f python3 tools/kernel_times.py melbourne delft; done; done; } > $P/${TAG}_last_arriver.txt 2>> $O/bench.err
   python3 -m pytest tests -q -m gpu > $P/${TAG}_pytest_gpu.log 2>&1
 fi
 ls -la $P
