@@ -33,6 +33,7 @@ struct pedn_sim {
   int node_waves = 8;  // register budget of node_kernel, see pedn_create
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
   int link_ns = 1;     // segments of 128 replicas per lane of the link update (launch_step); PEDN_LINK_NS=1|2
+  int max_degree = 0;     // largest number of incident corridors of a node
   size_t node_lds = 0;    // dynamic LDS bytes of node_kernel
   int second_launch = 0;  // launch_step: a launch followed node_kernel
   int fuse_link = 0;   // node_kernel<FUSE> also does the link update (the later of a corridor's two end waves): no link launch
@@ -600,6 +601,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       }
     }
     s->n_blocks = (int)bins.size();
+    for (int n = 0; n < N; ++n) s->max_degree = std::max(s->max_degree, deg(n));
+    if (const char* f = getenv("PEDN_NODE_MD")) if (atoi(f) == 8) s->max_degree = 8;  // diagnostic: the general instantiation
     {  // LDS of node_kernel: 8 (LP: 16) rows of 64 doubles + the m*m tiles of the fullest block
       int tiles = 1;
       for (const auto& bin : bins) {
@@ -948,14 +951,14 @@ int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
 typedef void (*node_kernel_fn)(DevView, int);
 static node_kernel_fn node_kernel_for(const pedn_sim* s) {
   const bool h = s->v.hist != 0;  // recent-history mode: the instantiations that mask the history rows
-  if (s->node_lp) return s->v.pr ? (h ? node_kernel<true, 8, true, true> : node_kernel<true, 8, true, false>)
-                                 : (h ? node_kernel<false, 8, true, true> : node_kernel<false, 8, true, false>);
-  if (s->fuse_link) return s->v.pr ? (h ? node_kernel<true, 8, false, true, true> : node_kernel<true, 8, false, false, true>)
-                                   : (h ? node_kernel<false, 8, false, true, true> : node_kernel<false, 8, false, false, true>);
-  if (s->v.pr) return s->node_waves == 8 ? (h ? node_kernel<true, 8, false, true> : node_kernel<true, 8, false, false>)
-                                         : (h ? node_kernel<true, 6, false, true> : node_kernel<true, 6, false, false>);
-  return s->node_waves == 8 ? (h ? node_kernel<false, 8, false, true> : node_kernel<false, 8, false, false>)
-                            : (h ? node_kernel<false, 6, false, true> : node_kernel<false, 6, false, false>);
+  const bool d6 = s->max_degree <= 6;  // loops and the row of turning fractions unrolled for 6 instead of 8 corridors per node
+#define PEDN_NK(PR_, W_, LP_, F_) (h ? (d6 ? node_kernel<PR_, W_, LP_, true, F_, 6> : node_kernel<PR_, W_, LP_, true, F_, 8>) \
+                                     : (d6 ? node_kernel<PR_, W_, LP_, false, F_, 6> : node_kernel<PR_, W_, LP_, false, F_, 8>))
+  if (s->node_lp) return s->v.pr ? PEDN_NK(true, 8, true, false) : PEDN_NK(false, 8, true, false);
+  if (s->fuse_link) return s->v.pr ? PEDN_NK(true, 8, false, true) : PEDN_NK(false, 8, false, true);
+  if (s->v.pr) return s->node_waves == 8 ? PEDN_NK(true, 8, false, false) : PEDN_NK(true, 6, false, false);
+  return s->node_waves == 8 ? PEDN_NK(false, 8, false, false) : PEDN_NK(false, 6, false, false);
+#undef PEDN_NK
 }
 
 // One step = node_kernel(t), then ONE launch with the link update of t and -- where they apply -- the turn probabilities of

@@ -615,7 +615,9 @@ template <bool HIST>
 __device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& Pa, const LinkP& Pb, int a, int b, int t, int r,
                                                 double da, double db, float pa, float pb);
 
-template <bool PR, int WAVES, bool LP, bool HIST, bool FUSE = false>
+// MD: degree the row / column loops and the row of turning fractions are unrolled for (the host picks 6 when no node of the
+// model has more incident corridors: 4 vector registers less in a kernel that lives on its last one)
+template <bool PR, int WAVES, bool LP, bool HIST, bool FUSE = false, int MD = PEDN_MAX_DEGREE>
 __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   // dynamic LDS, sized by the host for the fullest block (pedn_create: node_lds): a block of nodes of degree 3..4 needs 24 of
   // the 64 tiles a single degree-8 node would, and LDS a block does not hold lets the CU start the next block earlier
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0, co_prev = 0.0, ci_prev = 0.0;
   int lin = 0, lout = 0, kind = 0;
   float np_in = 0.0f, np_out = 0.0f;  // FUSE: num_pedestrians[t-1] of the slot's two links, kept for their update
-  double tfr[PEDN_MAX_DEGREE - 1];
+  double tfr[MD - 1];
 
   if (active) {
     kind = W.kind;
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       ci_prev = rowp(v.f64[F_CI], R64(F_CI, tp), lout, Lall, RS, r0)[lane];
       if (kind == 1) {
 #pragma unroll
-        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
+        for (int jj = 0; jj < MD - 1; ++jj)
           if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
       }
       r_i = 1e6;
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       }
       if (kind == 1) {
 #pragma unroll
-        for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj)
+        for (int jj = 0; jj < MD - 1; ++jj)
           if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
       }
       if (!Pin.sep) x.k_in = x.n_in / Pin.area32;
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     if (kind == 1) {
       // P[i][j] * s_i  (node.py:285)
 #pragma unroll
-      for (int jj = 0; jj < PEDN_MAX_DEGREE - 1; ++jj) {
+      for (int jj = 0; jj < MD - 1; ++jj) {
         if (jj < m - 1) {
           const int j = jj < slot ? jj : jj + 1;
           sPS[(size_t)(base + slot * m + j) * 64 + lane] = LP ? tfr[jj] : tfr[jj] * s_i;
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     double D = 0.0;
     bool first = true;
 #pragma unroll
-    for (int k = 0; k < PEDN_MAX_DEGREE; ++k) {
+    for (int k = 0; k < MD; ++k) {
       if (k < m && k != slot) {
         double x = sPS[(size_t)(base + k * m + slot) * 64 + lane];
         D = first ? x : D + x;
@@ -766,7 +768,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     }
     const double Ds = D != 0.0 ? D : 1e-5;
 #pragma unroll
-    for (int k = 0; k < PEDN_MAX_DEGREE; ++k) {
+    for (int k = 0; k < MD; ++k) {
       if (k < m && k != slot) {
         double a = sPS[(size_t)(base + k * m + slot) * 64 + lane];
         double b = r_i * (a / Ds);
@@ -783,11 +785,11 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   if (active) {
     if (kind == 1) {
 #pragma unroll
-      for (int j = 0; j < PEDN_MAX_DEGREE; ++j)
+      for (int j = 0; j < MD; ++j)
         if (j < m && j != slot) qo += sPS[(size_t)(base + slot * m + j) * 64 + lane];
       if (LP) {  // q = A_ub @ floor(x): the column sums were not formed by a column pass
 #pragma unroll
-        for (int k = 0; k < PEDN_MAX_DEGREE; ++k)
+        for (int k = 0; k < MD; ++k)
           if (k < m && k != slot) qi += sPS[(size_t)(base + k * m + slot) * 64 + lane];
       }
       if (!(qo > 0.0)) qo = 0.0;  // np.maximum(0, flows), node.py:299
