@@ -10,6 +10,9 @@ mkdir -p $O
   PEDN_FUSE_TP=0 python3 tools/gpu_fuzz.py 9600 9900
   PEDN_FUSE_TP=1 PEDN_TF_GENERAL=3 PEDN_TF_LDS_LIMIT=1 python3 tools/gpu_fuzz.py 9900 10200
   PEDN_FUSE_TP=1 python3 tools/gpu_fuzz.py 10200 10500 scenarios
+  echo "# the link update inside node_kernel (PEDN_FUSE_LINK=1, last arriver) and node_kernel unrolled for 8 corridors (PEDN_NODE_MD=8):"
+  PEDN_FUSE_LINK=1 python3 tools/gpu_fuzz.py 10700 11000
+  PEDN_NODE_MD=8 python3 tools/gpu_fuzz.py 11000 11200
   echo "# assign_flows_type 'optimal' (node LP):"
   PEDN_FUZZ_OPTIMAL=1 python3 tools/gpu_fuzz.py 10500 10700
   python3 tools/gpu_fuzz_rl.py 9000 9400
