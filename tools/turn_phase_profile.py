@@ -37,7 +37,7 @@ def main():
     o = o[o[:, 4] > 0]
     n = o[:, 4:5]
     ph = o[:, :3] / n
-    print(f"== {network} x {R}: {len(o)} rows; ticks of s_memtime (100 MHz: 1 tick = 10 ns) per wave, mean over {int(n[0, 0])} launches")
+    print(f"== {network} x {R}: {len(o)} rows; ticks of s_memtime (shader clock, about 2.4 GHz: 1000 ticks = 0.42 us) per wave, mean over {int(n[0, 0])} launches")
     print("   row  groups products | records+phase1  phase2  phase3 | total")
     order = np.argsort(-ph.sum(axis=1))
     for i in list(order[:12]) + list(order[-4:]):
