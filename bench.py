@@ -334,6 +334,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.share_device:
         local_rank = 0
+        args.backend = "gloo"         # RCCL refuses two ranks on one device; the rehearsal only needs the barrier / reductions
     dist = None
     if "RANK" in os.environ:          # launched by torch.distributed.run, also for N = 1
         import torch
