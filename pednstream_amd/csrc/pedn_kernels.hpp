@@ -602,9 +602,10 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 }
 
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
-// WAVES = waves per SIMD the register allocation aims at.  6: no spills, 3 blocks per CU -- best where the launch is bound by
-// HBM throughput (melbourne: 26.4 us against 28.0).  8: 64 VGPRs with 12 spilled, 4 blocks per CU -- best where it is bound by
-// latency, i.e. with dynamic junctions (delft: 36.6 us against 39.9).  pedn_create picks one per model.
+// WAVES = waves per SIMD the register allocation aims at.  8 (the default): 59..63 VGPRs, no vector spill, about 20 scalar
+// registers spilled into VGPR lanes, 4 blocks per CU.  6 (PEDN_NODE_WAVES=6, a diagnostic): no spill of any kind, but 94 scalar
+// registers leave 7 waves per SIMD -- slower on every model measured.  tests/test_kernel_resources.py
+// guards the budget: one more live register in the wrong place turns the scalar spills into 16 vector spills (+11 us).
 // LP: the node model is the linear programme of assign_flows_type 'optimal' instead of the classic proportional rule.
 // FUSE: the link update of t happens in this launch too.  A corridor's state needs inflow[t] / outflow[t] of both directions,
 // i.e. the results of the two slot waves at its two ends, which run in different workgroups: each wave publishes its two flows
@@ -620,7 +621,7 @@ __device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& P
 template <bool PR, int WAVES, bool LP, bool HIST, bool FUSE = false, int MD = PEDN_MAX_DEGREE>
 __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   // dynamic LDS, sized by the host for the fullest block (pedn_create: node_lds): a block of nodes of degree 3..4 needs 24 of
-  // the 64 tiles a single degree-8 node would, and LDS a block does not hold lets the CU start the next block earlier
+  // the 64 tiles a single degree-8 node would
   extern __shared__ double pedn_lds[];
   double* const sR = pedn_lds;                          // [8][64] receiving flow of each wave's outgoing link
   double* const sS = pedn_lds + 8 * 64;                 // [8][64] LP only: sending flow of each wave's incoming link
