@@ -215,6 +215,17 @@ int pedn_timer_end(pedn_sim* sim, float* ms);
  * kernel, ms[1] = node kernel, ms[2] = link kernel (0 when a kernel is not launched for this scenario). */
 int pedn_profile_step(pedn_sim* sim, int32_t t, float ms[3]);
 
+/* Steps t0 <= t < t1 under the launch plan pedn_run uses for such a range, every launch bracketed by its own dispatch
+ * timestamps (synchronises).  ms[0..2] = mean duration of a launch of {stand-alone turning fractions, node kernel, the launch
+ * behind it (link update and / or turning fractions of t + 1)}; *chains = 1 or 2: how many chains of launches ran side by
+ * side (2: the two halves of the replicas on two streams -- a launch then covers n_replicas / 2 and overlaps the other
+ * chain's launches, so per-launch bandwidths of the two chains add up). */
+int pedn_profile_run(pedn_sim* sim, int32_t t0, int32_t t1, float ms[3], int32_t* chains);
+
+/* launch plan of pedn_run for long ranges: 1 = one chain of launches on the engine's stream, 2 = the two halves of the
+ * replicas as two chains on two streams (the default from 1024 replicas; replicas are independent, results are the same) */
+int pedn_set_streams(pedn_sim* sim, int32_t n);
+
 /* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */
 int pedn_reset(pedn_sim* sim);
 

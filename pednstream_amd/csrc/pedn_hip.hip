@@ -35,6 +35,9 @@ struct pedn_sim {
   int link_ns = 1;     // segments of 128 replicas per lane of the link update (launch_step); PEDN_LINK_NS=1|2
   int max_degree = 0;     // largest number of incident corridors of a node
   size_t node_lds = 0;    // dynamic LDS bytes of node_kernel
+  hipStream_t stream2 = nullptr;   // second half of the replicas in pedn_run (two_streams)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int two_streams = 0;    // pedn_run launches the two halves of the batch on two streams (replicas are independent)
   int second_launch = 0;  // launch_step: a launch followed node_kernel
   int fuse_link = 0;   // node_kernel<FUSE> also does the link update (the later of a corridor's two end waves): no link launch
   int fuse_tp = 0;     // the link update and the next step's turn probabilities share one launch (launch_step)
@@ -287,6 +290,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   v.T1 = m->T + 1;
   v.R = n_replicas;
   v.RS = (n_replicas + 127) / 128 * 128;  // a link_kernel wave covers 128 replicas (2 per lane), a node_kernel wave 64
+  v.sub0 = 0;
+  v.subRS = v.RS;
   v.W = m->window;
   v.dt = m->dt;
   {  // history rows (DevView.m64 / m32)
@@ -326,6 +331,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   {
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; return fail(nullptr, PEDN_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
+    hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
     hipEventCreate(&s->ev0);
     hipEventCreate(&s->ev1);
   }
@@ -624,6 +632,12 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
     if (const char* f = getenv("PEDN_LINK_NS")) s->link_ns = atoi(f) == 2 ? 2 : 1;
     for (SlotRec& R : rec) { R.act = -1; R.lp = -1; }
+    // two chains of launches (one per half of the replicas) in pedn_run; PEDN_STREAMS=1|2, pedn_set_streams.  Default: models
+    // with dynamic turning-fraction rows from 1024 replicas -- their second launch is few long waves at 4 waves per SIMD, and the
+    // other half's node_kernel fills the machine meanwhile (delft x 1024: 51.7 -> 45.3 us per step).  Without such rows the gain
+    // is smaller (melbourne 38.8 -> 37.3) and the plan stays one chain, whose launches are the ones the roofline figures describe.
+    s->two_streams = v.RS >= 1024 && v.n_trow > 0;
+    if (const char* f = getenv("PEDN_STREAMS")) s->two_streams = atoi(f) == 2;
     // PEDN_FUSE_LINK=1: node_kernel<FUSE> does the link update too (the later of a corridor's two end waves) and the link launch
     // goes away.  Parity-green, but not faster (the update's arithmetic and its extra memory round trip land
     // on waves that hold a full CU's wave slots), so it is off unless asked for.
@@ -714,6 +728,9 @@ int pedn_destroy(pedn_sim* s) {
   }
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
+  if (s->stream2) hipStreamDestroy(s->stream2);
+  if (s->ev_fork) hipEventDestroy(s->ev_fork);
+  if (s->ev_join) hipEventDestroy(s->ev_join);
   if (s->stream) hipStreamDestroy(s->stream);
   delete s;
   return PEDN_OK;
@@ -966,16 +983,24 @@ static node_kernel_fn node_kernel_for(const pedn_sim* s) {
 // rl_observe; only pedn_rl_step asks for it).  ev != nullptr: per-launch start/stop events {turn_prob, node, link} for
 // pedn_profile_step.  Returns 1 through *observed when the observations were part of the launch.
 static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe = -1, bool* observed = nullptr,
-                       const double* fold_actions = nullptr) {
-  DevView& v = s->v;
+                       const double* fold_actions = nullptr, int half = -1) {
+  // half = -1: the whole batch on the engine's stream; 0 / 1: the first / second half of the replicas on stream / stream2 (the
+  // caller, pedn_run, launches both halves of a step and does the per-step bookkeeping once, after the second one)
+  DevView v = s->v;
+  hipStream_t stream = s->stream;
+  if (half >= 0) {
+    v.subRS = s->v.RS / 2;
+    v.sub0 = half * v.subRS;
+    if (half == 1) stream = s->stream2;
+  }
   DevView vn = v;                 // node_kernel's view: with the action rows when it applies the gater actions itself
   vn.rl_actions = fold_actions;
-  const unsigned rgroups = (unsigned)(v.RS / 64);
+  const unsigned rgroups = (unsigned)(v.subRS / 64);
   const bool groups = v.n_trow > 0, fused = groups && s->fuse_tp;
   const bool obs_fused = observe >= 0 && s->rl_ready && s->fuse_obs;
   auto launch = [&](auto kernel, dim3 grid, dim3 block, int e, auto... args) {
-    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, s->stream, ev[e], ev[e + 1], 0, args...);
-    else hipLaunchKernelGGL(kernel, grid, block, 0, s->stream, args...);
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev[e], ev[e + 1], 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
   };
   if (groups && s->tp_ready != t) {  // first step of an episode, a repeated or an out-of-order step
     const unsigned nb = (unsigned)((v.n_trow + 3) / 4) * rgroups;  // one wave per (row of a dynamic node, 64 replicas)
@@ -983,11 +1008,11 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     else { if (v.hist) launch(turn_frac_kernel<false, true>, dim3(nb), dim3(256), 0, v, t); else launch(turn_frac_kernel<false, false>, dim3(nb), dim3(256), 0, v, t); }
     s->tp_ran = 1;
   }
-  if (ev) hipExtLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, s->stream, ev[2], ev[3], 0, vn, t);
-  else hipLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, s->stream, vn, t);
+  if (ev) hipExtLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, ev[2], ev[3], 0, vn, t);
+  else hipLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, vn, t);
   // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
-  const int ns = (!v.pr && s->link_ns == 2 && v.RS % 256 == 0) ? 2 : 1;
-  const unsigned nlb = v.n_pairs_corr > 0 && !s->fuse_link ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.RS : v.RS / (2 * ns)) + 255) / 256) : 0u;
+  const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0) ? 2 : 1;
+  const unsigned nlb = v.n_pairs_corr > 0 && !s->fuse_link ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.subRS : v.subRS / (2 * ns)) + 255) / 256) : 0u;
   s->second_launch = 1;
   if (fused || obs_fused) {
     const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;
@@ -1009,7 +1034,7 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
       else PEDN_LT(false, false, 1);
     }
 #undef PEDN_LT
-    if (fused) s->tp_ready = t + 1;
+    if (fused && half != 0) s->tp_ready = t + 1;   // half 0: the second half of this step still has to see the old value
   } else if (nlb > 0) {
     if (v.pr) { if (v.hist) launch(link_kernel_pr<true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel_pr<false>, dim3(nlb), dim3(256), 4, v, t); }
     else if (ns == 2) { if (v.hist) launch(link_kernel<2, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel<2, false>, dim3(nlb), dim3(256), 4, v, t); }
@@ -1017,8 +1042,10 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   }
   else s->second_launch = 0;
   if (observed) *observed = obs_fused;
-  s->last_t = t;
-  ++s->step_epoch;
+  if (half != 0) {
+    s->last_t = t;
+    ++s->step_epoch;
+  }
   return PEDN_OK;
 }
 
@@ -1051,12 +1078,80 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   return PEDN_OK;
 }
 
+// pedn_run's plan for the range [t0, t1): the two halves of the batch as two chains of launches?
+static bool two_chains(const pedn_sim* s, int t0, int t1) {
+  return s->two_streams && t1 - t0 >= 8 && s->v.RS % 256 == 0;
+}
+
 int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (t0 < 1 || t1 > s->v.T1 || t0 > t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
-  for (int t = t0; t < t1; ++t) launch_step(s, t);
+  // Replicas are independent, so the two halves of the batch can run as two chains of launches on two streams: while one
+  // half is in its link update (few, long waves) the other half's node_kernel fills the machine, and the ramp and the tail of
+  // every launch overlap the other chain's work.  Forking and joining costs two cross-stream waits per CALL, so only ranges of
+  // several steps take this plan; everything else (single steps, RL steps, profiling) stays on the one stream.
+  if (two_chains(s, t0, t1)) {
+    HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
+    HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+    for (int t = t0; t < t1; ++t) {
+      launch_step(s, t, nullptr, -1, nullptr, nullptr, 0);
+      launch_step(s, t, nullptr, -1, nullptr, nullptr, 1);
+    }
+    HIP_TRY(s, hipEventRecord(s->ev_join, s->stream2));
+    HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
+  } else {
+    for (int t = t0; t < t1; ++t) launch_step(s, t);
+  }
   HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
+int pedn_set_streams(pedn_sim* s, int32_t n) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (n != 1 && n != 2) return fail(s, PEDN_E_ARG, "1 or 2 chains of launches");
+  s->two_streams = n == 2;
+  return PEDN_OK;
+}
+
+int pedn_profile_run(pedn_sim* s, int32_t t0, int32_t t1, float ms[3], int32_t* chains) {
+  if (!s || !ms || !chains) return fail(s, PEDN_E_ARG, "null argument");
+  if (t0 < 1 || t1 > s->v.T1 || t0 >= t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
+  HIP_TRY(s, hipSetDevice(s->device));
+  const bool two = two_chains(s, t0, t1);
+  const int halves = two ? 2 : 1, n = (t1 - t0) * halves;
+  std::vector<hipEvent_t> ev((size_t)n * 6);
+  for (auto& e : ev) HIP_TRY(s, hipEventCreate(&e));
+  std::vector<int> tp_ran((size_t)n, 0), second((size_t)n, 0);
+  if (two) {
+    HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
+    HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+  }
+  for (int t = t0, k = 0; t < t1; ++t)
+    for (int h = 0; h < halves; ++h, ++k) {
+      s->tp_ran = 0;
+      launch_step(s, t, &ev[(size_t)k * 6], -1, nullptr, nullptr, two ? h : -1);
+      tp_ran[k] = s->tp_ran;
+      second[k] = s->second_launch;
+    }
+  if (two) {
+    HIP_TRY(s, hipEventRecord(s->ev_join, s->stream2));
+    HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
+  }
+  HIP_TRY(s, hipGetLastError());
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  double sum[3] = {0, 0, 0};
+  int cnt[3] = {0, 0, 0};
+  for (int k = 0; k < n; ++k) {
+    float d = 0.0f;
+    if (tp_ran[k]) { HIP_TRY(s, hipEventElapsedTime(&d, ev[(size_t)k * 6], ev[(size_t)k * 6 + 1])); sum[0] += d; ++cnt[0]; }
+    HIP_TRY(s, hipEventElapsedTime(&d, ev[(size_t)k * 6 + 2], ev[(size_t)k * 6 + 3]));
+    sum[1] += d; ++cnt[1];
+    if (second[k]) { HIP_TRY(s, hipEventElapsedTime(&d, ev[(size_t)k * 6 + 4], ev[(size_t)k * 6 + 5])); sum[2] += d; ++cnt[2]; }
+  }
+  for (int i = 0; i < 3; ++i) ms[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : 0.0f;
+  *chains = halves;
+  for (auto& e : ev) hipEventDestroy(e);
   return PEDN_OK;
 }
 

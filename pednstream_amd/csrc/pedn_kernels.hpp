@@ -219,11 +219,11 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
   __shared__ double sAcc[(PEDN_MAX_DEGREE - 1) * 64];  // coop rows: the turns' sums on their way to wave 0
   constexpr int NE = PEDN_MAX_DEGREE - 1;
   const int RS = v.RS;
-  const unsigned rgroups = (unsigned)(RS / 64);
+  const unsigned rgroups = (unsigned)(v.subRS / 64);
   const int lane = (int)(threadIdx.x & 63);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int row = (int)(block / rgroups) * 4 + wave;
-  const int r = (int)(block % rgroups) * 64 + lane;
+  const int r = v.sub0 + (int)(block % rgroups) * 64 + lane;
   if (row >= v.n_trow) return;  // wave-uniform; no barrier below
   const int* rw = v.trow_words + (size_t)row * PEDN_TROW_WORDS;
   const int w0 = rw[lane], w1 = rw[64 + lane];
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   // blockIdx.x = replica group (fastest in dispatch order): blocks launched together touch neighbouring 512-byte chunks
   // of the same history rows
-  const int r0 = (int)blockIdx.x * 64;
+  const int r0 = v.sub0 + (int)blockIdx.x * 64;
   const int r = r0 + lane;
   const int tp = t - 1;
 #ifdef PEDN_PHASE_PROFILE
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
 
   if (LP) {
     if (active && kind == 1 && slot == 0) {  // one wave solves the node's programme for its 64 replicas
-      const size_t w = (size_t)W.lp * gridDim.x + blockIdx.x;
+      const size_t w = (size_t)W.lp * (size_t)(RS / 64) + (size_t)(r0 >> 6);
       if (!lp_solve(v.lp_ws + w * v.lp_stride, v.lp_basis + w * v.lp_bstride, m, &sS[wave * 64], &sR[wave * 64], &sPS[(size_t)base * 64], lane))
         fl |= PEDN_F_LP;
     }
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       __hip_atomic_store(p_in, qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's flows have left the chip's caches before it signals
       int arrived = 0;
-      if (lane == 0) arrived = __hip_atomic_fetch_add(&v.arrive[(size_t)corr * gridDim.x + blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) arrived = __hip_atomic_fetch_add(&v.arrive[(size_t)corr * (size_t)(RS / 64) + (size_t)(r0 >> 6)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       arrived = __builtin_amdgcn_readfirstlane(arrived);
       if (arrived & 1) {  // the other end of the corridor has published: Network.update_link_states for both directions
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -898,10 +898,10 @@ __device__ __forceinline__ void st2(float* p, size_t i, float a, float b) { *rei
 // wave): used inside link_turn_kernel, where the turning-fraction waves compete for the wave slots.
 template <int NS, bool HIST>
 __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
-  const int RS = v.RS, L = v.L, Lall = v.Lall, H = RS / (2 * NS);  // lanes per corridor
+  const int RS = v.RS, L = v.L, Lall = v.Lall, H = v.subRS / (2 * NS);  // lanes per corridor
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)H));
   const int lh = (int)(gid % (size_t)H);
-  const int r0 = (lh / 64) * (128 * NS) + (lh % 64) * 2;  // first replica of segment 0; segment s starts 128 s further
+  const int r0 = v.sub0 + (lh / 64) * (128 * NS) + (lh % 64) * 2;  // first replica of segment 0; segment s starts 128 s further
   if (p >= v.n_pairs_corr) return;
   const CorrRec& C = v.corr_rec[p];  // wave-uniform
   const int a = C.a, b = C.b;
@@ -1003,8 +1003,8 @@ __device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& P
 template <bool HIST>
 __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid) {
   const int RS = v.RS, L = v.L, Lall = v.Lall;
-  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)RS));
-  const int r = (int)(gid % (size_t)RS);
+  int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)v.subRS));
+  const int r = v.sub0 + (int)(gid % (size_t)v.subRS);
   if (p >= v.n_pairs_corr) return;
   const CorrRec& C = v.corr_rec[p];
   const int a = C.a, b = C.b;
@@ -1070,9 +1070,9 @@ __device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& 
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
-  const unsigned rgroups = (unsigned)(RS / 64);
+  const unsigned rgroups = (unsigned)(v.subRS / 64);
   const int ag = (int)(block / rgroups);
-  const int r = (int)(block % rgroups) * 64 + lane;
+  const int r = v.sub0 + (int)(block % rgroups) * 64 + lane;
   if (ag >= q.n_agents) return;  // block-uniform
   const int la = q.agent_link_ptr[ag], n = q.agent_link_ptr[ag + 1] - la;
   const int type = q.agent_type[ag];

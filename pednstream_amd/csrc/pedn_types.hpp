@@ -98,6 +98,7 @@ struct DevView {
   // flow looks back an unbounded, data-dependent number of steps into them), the others are rings of mask + 1 rows.
   int32_t m64[7], m32[6];
   int32_t hist;
+  int32_t sub0, subRS;  // replicas [sub0, sub0 + subRS) are this launch's share (the whole batch, or one half of it per stream)
   // gater actions applied inside node_kernel (pedn_rl_step, gater-only agent sets): row-major [R][rl_A] widths, NaN = no action
   const double* rl_actions;
   int32_t rl_A;

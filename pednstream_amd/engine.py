@@ -150,6 +150,8 @@ def _load():
         "pedn_timer_end": (C.c_int, [P, C.POINTER(C.c_float)]),
         "pedn_reset": (C.c_int, [P]),
         "pedn_profile_step": (C.c_int, [P, C.c_int32, C.POINTER(C.c_float)]),
+        "pedn_profile_run": (C.c_int, [P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+        "pedn_set_streams": (C.c_int, [P, C.c_int32]),
         "pedn_set_link_params": (C.c_int, [P, _F64P, _F64P, _F64P, _I32P, _I32P, _F32P]),
         "pedn_set_od_weights_per_replica": (C.c_int, [P, _F64P]),
         "pedn_rl_configure": (C.c_int, [P, C.POINTER(RlDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -180,7 +182,7 @@ def lib():
 EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand", "pedn_set_demand_matrix", "pedn_set_demand_rows", "pedn_get_demand", "pedn_draw_demand",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
-           "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_rl_configure",
+           "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_set_streams", "pedn_rl_configure",
            "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
            "pedn_set_od_weights_per_replica"]
 
@@ -366,6 +368,18 @@ class Engine:
         ms = (C.c_float * 3)()
         self._ck(self._lib.pedn_profile_step(self._h, int(t), ms))
         return tuple(float(x) for x in ms)
+
+    def profile_run(self, t0, t1):
+        """Steps t0 <= t < t1 under run()'s launch plan with every launch timed: ((turn_ms, node_ms, second_ms) mean per launch,
+        chains) -- chains = 2 when the two halves of the replicas ran as two chains of launches on two streams."""
+        ms = (C.c_float * 3)()
+        chains = C.c_int32(0)
+        self._ck(self._lib.pedn_profile_run(self._h, int(t0), int(t1), ms, C.byref(chains)))
+        return tuple(float(x) for x in ms), int(chains.value)
+
+    def set_streams(self, n):
+        """Launch plan of run() for long ranges: 1 chain of launches, or 2 (the halves of the replica batch on two streams)."""
+        self._ck(self._lib.pedn_set_streams(self._h, int(n)))
 
     # -- batched RL glue
     def rl_configure(self, agent_type, agent_link_ptr, agent_links, obs_mode, normalize, reward_mode, max_delta_sep,

@@ -371,6 +371,69 @@ def test_per_replica_widths_and_turning_fractions_via_replica_scope():
     net.close()
 
 
+@pytest.mark.parametrize("name,steps", [("nine_intersections", 150), ("delft", 40), ("long_corridor", 150), ("melbourne", 60)])
+def test_two_stream_plan_gives_identical_histories(name, steps, monkeypatch):
+    """pedn_run launches the two halves of a large batch as two chains on two streams (replicas are independent; the default
+    from 1024 replicas).  Same bits as the one-stream plan in every field and every replica, also when the run is cut into
+    several calls, continues after a setter, and after a reset; turning fractions and error flags included."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    def history(streams):
+        monkeypatch.setenv("PEDN_STREAMS", streams)
+        np.random.seed(7)
+        net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=256, rng_seed=11)
+        e = net.engine()
+        cut = steps // 3
+        net.run(1, cut)                                   # two calls: the second one starts from fused turning fractions
+        link = next(iter(net.links.values()))
+        link.back_gate_width = link.back_gate_width       # a setter between the calls (drops the fused fractions)
+        net.run(cut, steps)
+        out = {f: e.read_block(LINK_FIELDS[f][0], 0, steps) for f in ALL_FIELDS}
+        out["tf"] = np.stack([np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 127, 128, 255)])
+        out["flags"] = e.error_flags()[1]
+        e.reset()
+        net.run(1, steps)
+        out2 = {f: e.read_block(LINK_FIELDS[f][0], 0, steps) for f in ALL_FIELDS}
+        net.close()
+        return out, out2
+
+    a, a2 = history("1")
+    b, b2 = history("2")
+    for f in a:
+        assert np.array_equal(a[f], b[f]), f
+    for f in a2:
+        assert np.array_equal(a2[f], b2[f]), f
+        assert np.array_equal(a[f], a2[f]), f             # the second episode repeats the first
+
+
+def test_profile_run_uses_and_reports_the_launch_plan():
+    """pedn_profile_run steps the simulation under pedn_run's plan with every launch timed: the plan it reports follows
+    pedn_set_streams and the length of the range, and the histories equal an untimed run's."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    np.random.seed(7)
+    net = NetworkEnvGenerator(DATA).create_network("nine_intersections", verbose=False, n_replicas=256, rng_seed=11)
+    e = net.engine()
+    e.set_streams(2)
+    ms, chains = e.profile_run(1, 40)
+    assert chains == 2 and ms[1] > 0 and ms[2] > 0
+    ms, chains = e.profile_run(40, 44)            # too short to pay for the fork and the join
+    assert chains == 1
+    e.set_streams(1)
+    ms, chains = e.profile_run(44, 80)
+    assert chains == 1 and ms[1] > 0
+    timed = {f: e.read_block(LINK_FIELDS[f][0], 0, 80) for f in ALL_FIELDS}
+    e.reset()
+    net.run(1, 80)
+    for f in ALL_FIELDS:
+        assert np.array_equal(timed[f], e.read_block(LINK_FIELDS[f][0], 0, 80)), f
+    with pytest.raises(Exception):
+        e.set_streams(3)
+    net.close()
+
+
 @pytest.mark.parametrize("fuse_tp,general,lds_limit,fuse_link", [("1", "0", "64", "0"), ("0", "0", "64", "0"), ("1", "3", "1", "0"), ("1", "0", "64", "1")])
 def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, fuse_link, monkeypatch):
     """(with the next step's turn probabilities fused into the link update launch, and launched on their own: nine of the
