@@ -158,6 +158,47 @@ def test_vectorised_randomisation_draws_the_reference_ranges_for_every_env():
     env.close()
 
 
+def test_two_chains_of_launches_with_per_replica_scenarios_and_with_the_node_lp(monkeypatch):
+    """The two-stream plan of pedn_run (tests/test_gpu_parity.py) through the kernel instantiations it does not reach there:
+    per-replica link parameters / OD weights / demand (node_kernel<PR>, link_kernel_pr, turn_frac_kernel<PR>) and the node LP
+    (its tableau workspace is indexed by replica group).  Same bits as one chain of launches."""
+    from pednstream_amd import NetworkEnvGenerator
+    from pednstream_amd.network import LINK_FIELDS
+    from pednstream_amd.rl_env import VecPedNetEnv
+
+    def scenario_run(streams):
+        monkeypatch.setenv("PEDN_STREAMS", streams)
+        np.random.seed(3)
+        env = VecPedNetEnv("45_intersections", n_envs=256, obs_mode="option3", data_dir=DATA, seed=9)
+        env.reset(options={"randomize": True, "mode": "vectorised"}, seed=5)
+        env.network.run(1, 60)
+        e = env.network.engine()
+        out = {f: e.read_block(LINK_FIELDS[f][0], 0, 60) for f in LINK_FIELDS}
+        out["flags"] = e.error_flags()[1]
+        env.close()
+        return out
+
+    def lp_run(streams):
+        monkeypatch.setenv("PEDN_STREAMS", streams)
+        gen = NetworkEnvGenerator(DATA)
+        np.random.seed(7)
+        gen.network_data = gen.load_network_data("nine_intersections")
+        gen.config["params"]["assign_flows_type"] = "optimal"
+        net = gen.create_network("nine_intersections", verbose=False, n_replicas=256, rng_seed=11)
+        assert net.assign_flows_type == "optimal"
+        net.run(1, 60, check=False)
+        e = net.engine()
+        out = {f: e.read_block(LINK_FIELDS[f][0], 0, 60) for f in LINK_FIELDS}
+        out["flags"] = e.error_flags()[1]
+        net.close()
+        return out
+
+    for run in (scenario_run, lp_run):
+        a, b = run("1"), run("2")
+        for f in a:
+            assert np.array_equal(a[f], b[f]), (run.__name__, f)
+
+
 @pytest.mark.parametrize("mode", ["reference", "vectorised"])
 def test_randomised_reset_is_a_function_of_the_seed(mode):
     """Same seed -> the same scenarios, demand and trajectories (on a fresh env and on a reused one); another seed -> others."""
