@@ -12,7 +12,9 @@ and the max-over-ranks reduction of the wall time.
 
 value = links x replicas(all ranks) x K / wall-seconds (max over ranks) of the timed region; inputs are resident in
 HBM before the region starts.  The line also carries
-  roofline     dominant kernel (node_kernel): `achieved` / `frac` = ALGORITHMIC bytes per launch / dispatch duration vs 8 TB/s
+  roofline     dominant kernel (node_kernel): `achieved` / `frac` = ALGORITHMIC bytes per launch / dispatch duration vs 8 TB/s;
+               `traffic` = memory-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, run
+               as child processes BEFORE this process touches the GPU (N = 1; the committed profiles/ summary otherwise)
                (the contract figure), next to `frac_counter` (bytes the PMC counters saw / the same duration), the whole step
                (`whole_step_frac`, 212 B per link-update) and `traffic_bytes_per_link_update`
   cpu_baseline the C restatement under oracle/ timed on this host's cores (1 thread and all cores, CPU model stated) on a
@@ -114,11 +116,67 @@ def cpu_baseline(model, net, origin_nodes, network, seconds_target=7.0):
     return out
 
 
+LIVE_TRAFFIC = {}     # network -> {"node_kernel": bytes per launch, ...} measured by live_traffic() before anything touched the GPU
+
+
+def live_traffic(networks, replicas, history):
+    """Memory-side bytes per launch of the step kernels, measured NOW: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes
+    (separate runs, as MI355X_MICROARCH.md prescribes) of a short run of this same command as child processes, plus the two
+    calibration launches of tools/pmc_calibrate.py that fix the gfx950 unit of FETCH_SIZE.  Must run before this process
+    initialises the GPU (a child of a process that holds the GPU must not exec).  Any failure leaves LIVE_TRAFFIC empty and
+    the line falls back to the committed profiles/rNN_pmc.json, labelled as such."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+
+    roc = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(roc) or os.environ.get("PEDN_BENCH_CHILD"):
+        return
+    tmp = tempfile.mkdtemp(prefix="pedn_pmc_", dir="/tmp")
+    env = dict(os.environ, PEDN_BENCH_CHILD="1", TMPDIR="/tmp")
+
+    def counters(counter, tag, cmd):
+        d = os.path.join(tmp, tag)
+        subprocess.run([roc, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+        by = {}
+        for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
+            name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "")
+            by.setdefault(name, []).append(float(r["Counter_Value"]))
+        return by
+
+    try:
+        cal = [sys.executable, os.path.join(ROOT, "tools", "pmc_calibrate.py")]
+        fetch_factor = round(2 * (1 << 26) * 8 / (counters("FETCH_SIZE", "cf", cal)["device_math_kernel"][0] * 1024), 2)
+        write_factor = round((1 << 26) * 8 / (counters("WRITE_SIZE", "cw", cal)["device_math_kernel"][0] * 1024), 2)
+        for network in networks:
+            cmd = [sys.executable, os.path.abspath(__file__), "--network", network, "--replicas", str(replicas), "--history", history,
+                   "--steps", "48", "--warmup", "20", "--no-cpu-baseline", "--no-extra"]
+            f, w = counters("FETCH_SIZE", "pf_" + network, cmd), counters("WRITE_SIZE", "pw_" + network, cmd)
+            out = {"fetch_factor": fetch_factor, "write_factor": write_factor}
+            for k in f:
+                if k in ("node_kernel", "link_kernel", "link_turn_kernel") and k in w:
+                    skip = len(f[k]) // 4          # the warm-up launches (and the first, cold ones)
+                    out[k] = statistics.mean(f[k][skip:]) * 1024 * fetch_factor + statistics.mean(w[k][skip:]) * 1024 * write_factor
+            LIVE_TRAFFIC[network] = out
+    except Exception as exc:    # noqa: BLE001 -- a profiler that is missing or refuses must not cost the bench line
+        print(f"bench.py: live PMC passes failed ({type(exc).__name__}: {exc}); traffic falls back to the committed summary", file=sys.stderr)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024):
     """Memory-side bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN[_network]_pmc.json, written by
     tools/summarize_profiles.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  bench.py cannot
     collect PMC counters on itself: the number rides along, labelled with its file, only for the workload it was measured on."""
     import glob
+    if network in LIVE_TRAFFIC and kernel in LIVE_TRAFFIC[network]:
+        lt = LIVE_TRAFFIC[network]
+        return lt[kernel], (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command run as child processes before the timed "
+                            f"run (FETCH_SIZE x {lt['fetch_factor']}, WRITE_SIZE x {lt['write_factor']} from two calibration launches)")
     if replicas != 1024:
         return None, None
     suffix = "" if network == "melbourne" else f"_{network}"
@@ -353,6 +411,7 @@ def main():
     ap.add_argument("--network", default="melbourne")
     ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc child passes; roofline.traffic then comes from profiles/")
     ap.add_argument("--no-extra", action="store_true", help="skip the delft x 1024 (BASELINE config #3) measurement that rides along at N = 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                     "multi-rank path on one GPU)")
@@ -370,6 +429,8 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
         if args.gpus > 1:             # nothing has touched the GPU yet: the ranks run in a child, this process only relays its exit code
             raise SystemExit(spawn_ranks(args, sys.argv[1:]))
+        if args.gpus == 1 and not args.no_extra and not args.rl and not args.no_live_traffic:
+            live_traffic([args.network] + (["delft"] if args.network == "melbourne" and args.replicas == 1024 else []), args.replicas, args.history)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
