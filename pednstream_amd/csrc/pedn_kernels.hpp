@@ -1286,6 +1286,9 @@ __global__ void draw_demand_kernel(double* dst, size_t row, int T1, int R, int R
   dst[(row * T1 + t) * RS + r] = val;
 }
 
+// first work on the engine's second stream (pedn_hip.hip: warm_second_stream)
+__global__ void noop_kernel() {}
+
 __global__ void device_math_kernel(int op, int n, const double* a, const double* b, uint32_t k0, uint32_t k1, double* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
