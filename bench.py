@@ -141,7 +141,7 @@ def live_traffic(networks, replicas, history):
     def counters(counter, tag, cmd):
         d = os.path.join(tmp, tag)
         subprocess.run([roc, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
         by = {}
         for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
             name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "")
