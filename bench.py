@@ -128,6 +128,7 @@ def live_traffic(networks, replicas, history):
     import csv
     import glob
     import shutil
+    import signal
     import statistics
     import subprocess
     import tempfile
@@ -140,8 +141,18 @@ def live_traffic(networks, replicas, history):
 
     def counters(counter, tag, cmd):
         d = os.path.join(tmp, tag)
-        subprocess.run([roc, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
+        # own process group: a pass that hangs is killed together with the program under the profiler, so that nothing of it is
+        # left on the GPU when the timed run starts
+        proc = subprocess.Popen([roc, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = proc.wait(timeout=90)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait()
+            raise
+        if rc != 0:
+            raise RuntimeError(f"rocprofv3 --pmc {counter} exited with {rc}")
         by = {}
         for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
             name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "")
