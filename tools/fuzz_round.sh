@@ -13,6 +13,8 @@ mkdir -p $O
   echo "# the link update inside node_kernel (PEDN_FUSE_LINK=1, last arriver) and node_kernel unrolled for 8 corridors (PEDN_NODE_MD=8):"
   PEDN_FUSE_LINK=1 python3 tools/gpu_fuzz.py 10700 11000
   PEDN_NODE_MD=8 python3 tools/gpu_fuzz.py 11000 11200
+  echo "# the two halves of the batch as two chains of launches on two streams against one chain (256 replicas per network):"
+  python3 tools/gpu_fuzz_chains.py 12000 12150
   echo "# assign_flows_type 'optimal' (node LP):"
   PEDN_FUZZ_OPTIMAL=1 python3 tools/gpu_fuzz.py 10500 10700
   python3 tools/gpu_fuzz_rl.py 9000 9400
