@@ -1138,7 +1138,12 @@ int pedn_profile_run(pedn_sim* s, int32_t t0, int32_t t1, float ms[3], int32_t* 
   HIP_TRY(s, hipSetDevice(s->device));
   const bool two = two_chains(s, t0, t1);
   const int halves = two ? 2 : 1, n = (t1 - t0) * halves;
-  std::vector<hipEvent_t> ev((size_t)n * 6);
+  struct Events {  // destroyed on every way out of the function
+    std::vector<hipEvent_t> e;
+    ~Events() { for (hipEvent_t x : e) if (x) hipEventDestroy(x); }
+  } evs;
+  evs.e.assign((size_t)n * 6, nullptr);
+  std::vector<hipEvent_t>& ev = evs.e;
   for (auto& e : ev) HIP_TRY(s, hipEventCreate(&e));
   std::vector<int> tp_ran((size_t)n, 0), second((size_t)n, 0);
   if (two) {
@@ -1169,7 +1174,6 @@ int pedn_profile_run(pedn_sim* s, int32_t t0, int32_t t1, float ms[3], int32_t* 
   }
   for (int i = 0; i < 3; ++i) ms[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : 0.0f;
   *chains = halves;
-  for (auto& e : ev) hipEventDestroy(e);
   return PEDN_OK;
 }
 
