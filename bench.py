@@ -6,20 +6,25 @@
 
 A "step" is one network_loading(t) over the whole replica batch of one GPU.  Workload at N = 1: the Melbourne network
 (341 nodes, 938 directed links, T = 500) x 1024 concurrent replicas, every replica with its own RNG key and its own
-Poisson origin demand, histories resident in HBM in full-record mode.  N > 1: the replica ensemble is sharded, 1024
-replicas per GPU (weak scaling), no collective on the step path; torch.distributed (RCCL) is used only for the barriers
-and the max-over-ranks reduction of the wall time.
+Poisson origin demand, histories resident in HBM in full-record mode.  N > 1: the replica ensemble is sharded over the ranks with
+no collective on the step path; torch.distributed (RCCL) is used only for the barriers, the max-over-ranks reduction of the
+wall time and the count of ranks that took part.  --replicas R: R replicas on every GPU ("scaling": "weak"; BASELINE config #4's
+shape is --replicas 512 on 8 GPUs); --total-replicas M: M replicas in all, M / N per GPU ("scaling": "strong").
 
 value = links x replicas(all ranks) x K / wall-seconds (max over ranks) of the timed region; inputs are resident in
 HBM before the region starts.  The line also carries
-  roofline     dominant kernel (node_kernel): `achieved` / `frac` = ALGORITHMIC bytes per launch / dispatch duration vs 8 TB/s;
-               `traffic` = memory-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, run
-               as child processes BEFORE this process touches the GPU (N = 1; the committed profiles/ summary otherwise)
-               (the contract figure), next to `frac_counter` (bytes the PMC counters saw / the same duration), the whole step
-               (`whole_step_frac`, 212 B per link-update) and `traffic_bytes_per_link_update`
+  roofline     dominant kernel (node_kernel).  `traffic` = memory-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+               passes of this same command, run as child processes BEFORE this process touches the GPU (N = 1; the committed
+               profiles/ summary otherwise).  `achieved` / `frac` = those MOVED bytes / the launch's duration (dispatch timestamps)
+               vs 8 TB/s when the passes succeeded; the contract figure (ALGORITHMIC bytes per launch, 164 B per link-update, /
+               the same duration) is `achieved_algorithmic` / `frac_algorithmic` -- and is what `achieved` / `frac` fall back to
+               without live counters (`basis` says which).  `working_set_bytes_per_step` + `fits_infinity_cache`: whether "hbm"
+               means HBM for this batch; the whole step is `whole_step_frac` (212 B per link-update) / `whole_step_frac_counter`
   cpu_baseline the C restatement under oracle/ timed on this host's cores (1 thread and all cores, CPU model stated) on a
                bounded sample of the same workload + the derived reference-Python equivalent (profiles/cpu_calibration.json)
-  extra        BASELINE config #3 (delft x 1024) measured in the same run (N = 1 only; --no-extra skips it)
+  extra        measured in the same run (N = 1 only; --no-extra skips them): BASELINE config #3 (delft x 1024); the headline
+               network at 4096 replicas (working set beyond the Infinity Cache) with its own counter passes; BASELINE config #5
+               (45_intersections x 2048 envs, batched RL step, env-steps/s) with a shared scenario and with per-env randomised ones
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment starts its N ranks itself (torch.distributed.run as a
 child process, before anything touches the GPU) and exits with the child's code; a WORLD_SIZE that disagrees with --gpus
@@ -116,13 +121,14 @@ def cpu_baseline(model, net, origin_nodes, network, seconds_target=7.0):
     return out
 
 
-LIVE_TRAFFIC = {}     # network -> {"node_kernel": bytes per launch, ...} measured by live_traffic() before anything touched the GPU
+LIVE_TRAFFIC = {}     # (network, replicas) -> {"node_kernel": bytes per launch, ...} measured by live_traffic() before anything touched the GPU
 
 
-def live_traffic(networks, replicas, history):
+def live_traffic(workloads, history):
     """Memory-side bytes per launch of the step kernels, measured NOW: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes
     (separate runs, as MI355X_MICROARCH.md prescribes) of a short run of this same command as child processes, plus the two
-    calibration launches of tools/pmc_calibrate.py that fix the gfx950 unit of FETCH_SIZE.  Must run before this process
+    calibration launches of tools/pmc_calibrate.py that fix the gfx950 unit of FETCH_SIZE.  workloads: (network, replicas)
+    pairs.  Must run before this process
     initialises the GPU (a child of a process that holds the GPU must not exec).  Any failure leaves LIVE_TRAFFIC empty and
     the line falls back to the committed profiles/rNN_pmc.json, labelled as such."""
     import csv
@@ -163,16 +169,16 @@ def live_traffic(networks, replicas, history):
         cal = [sys.executable, os.path.join(ROOT, "tools", "pmc_calibrate.py")]
         fetch_factor = round(2 * (1 << 26) * 8 / (counters("FETCH_SIZE", "cf", cal)["device_math_kernel"][0] * 1024), 2)
         write_factor = round((1 << 26) * 8 / (counters("WRITE_SIZE", "cw", cal)["device_math_kernel"][0] * 1024), 2)
-        for network in networks:
+        for network, replicas in workloads:
             cmd = [sys.executable, os.path.abspath(__file__), "--network", network, "--replicas", str(replicas), "--history", history,
                    "--steps", "48", "--warmup", "20", "--no-cpu-baseline", "--no-extra"]
-            f, w = counters("FETCH_SIZE", "pf_" + network, cmd), counters("WRITE_SIZE", "pw_" + network, cmd)
+            f, w = counters("FETCH_SIZE", f"pf_{network}_{replicas}", cmd), counters("WRITE_SIZE", f"pw_{network}_{replicas}", cmd)
             out = {"fetch_factor": fetch_factor, "write_factor": write_factor}
             for k in f:
                 if k in ("node_kernel", "link_kernel", "link_turn_kernel") and k in w:
                     skip = len(f[k]) // 4          # the warm-up launches (and the first, cold ones)
                     out[k] = statistics.mean(f[k][skip:]) * 1024 * fetch_factor + statistics.mean(w[k][skip:]) * 1024 * write_factor
-            LIVE_TRAFFIC[network] = out
+            LIVE_TRAFFIC[(network, replicas)] = out
     except Exception as exc:    # noqa: BLE001 -- a profiler that is missing or refuses must not cost the bench line
         print(f"bench.py: live PMC passes failed ({type(exc).__name__}: {exc}); traffic falls back to the committed summary", file=sys.stderr)
     finally:
@@ -184,8 +190,8 @@ def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024):
     tools/summarize_profiles.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  bench.py cannot
     collect PMC counters on itself: the number rides along, labelled with its file, only for the workload it was measured on."""
     import glob
-    if network in LIVE_TRAFFIC and kernel in LIVE_TRAFFIC[network]:
-        lt = LIVE_TRAFFIC[network]
+    if (network, replicas) in LIVE_TRAFFIC and kernel in LIVE_TRAFFIC[(network, replicas)]:
+        lt = LIVE_TRAFFIC[(network, replicas)]
         return lt[kernel], (f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command run as child processes before the timed "
                             f"run (FETCH_SIZE x {lt['fetch_factor']}, WRITE_SIZE x {lt['write_factor']} from two calibration launches)")
     if replicas != 1024:
@@ -202,49 +208,69 @@ def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024):
     return None, None
 
 
-def bench_rl(args):
+def measure_rl(network, B, steps, warmup, history, randomized=False):
     """BASELINE config #5: env-steps/s of the batched RL step (action clipping + network_loading + observations + rewards)
-    on 45_intersections x 2048 envs, obs option3, action_gap 1, uniform random actions resident in HBM."""
+    on `network` x B envs, obs option3, action_gap 1, uniform random actions resident in HBM.  randomized: the envs were reset
+    with options={'randomize': True} first (rl/pz_pednet_env.py:143-193, src/utils/env_loader.py:160-181): every env carries its
+    own link parameters, OD weights and demand -- the per-replica-parameter kernels."""
     import torch
 
     from pednstream_amd.rl_env import VecPedNetEnv
 
-    B = args.replicas
-    env = VecPedNetEnv(args.network, n_envs=B, obs_mode="option3", action_gap=1, seed=0, data_dir=os.path.join(ROOT, "data"),
-                       history=args.history)
+    env = VecPedNetEnv(network, n_envs=B, obs_mode="option3", action_gap=1, seed=0, data_dir=os.path.join(ROOT, "data"), history=history)
     e = env.network.engine()
+    reset_s = None
+    if randomized:
+        np.random.seed(0)
+        t0 = time.perf_counter()
+        env.reset(options={"randomize": True}, seed=0)
+        e.synchronize()
+        reset_s = time.perf_counter() - t0
     T = env.simulation_steps
-    K = min(args.steps, T - 1 - args.warmup)
+    K = min(steps, T - 1 - warmup)
     gen = torch.Generator(device="cuda").manual_seed(0)
     hi = torch.as_tensor(env.action_high, device="cuda", dtype=torch.float64)
-    acts = torch.rand((args.warmup + K, B, env.n_actions), generator=gen, device="cuda", dtype=torch.float64) * hi
+    acts = torch.rand((warmup + K, B, env.n_actions), generator=gen, device="cuda", dtype=torch.float64) * hi
     torch.cuda.synchronize()
     row = B * env.n_actions * 8
     t = 1
-    for k in range(args.warmup):
+    for k in range(warmup):
         e.rl_step_device(acts.data_ptr() + k * row, t)
         t += 1
     e.synchronize()
     e.timer_begin()
     t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + K):
+    for k in range(warmup, warmup + K):
         e.rl_step_device(acts.data_ptr() + k * row, t)
         t += 1
     dev_ms = e.timer_end()
     wall = time.perf_counter() - t0
     rc, _ = e.error_flags()
     assert rc == 0
+    L = e.n_links
     out = {"metric": "env-steps/sec (replicas x steps/sec, incl. action apply, observations, rewards)", "value": B * K / wall,
-           "unit": "env-steps/s", "n_gpus": 1, "steps": K, "warmup": args.warmup, "ms_per_step": wall / K * 1e3,
+           "unit": "env-steps/s", "n_gpus": 1, "steps": K, "warmup": warmup, "ms_per_step": wall / K * 1e3,
            "device_ms_per_step": dev_ms / K, "higher_is_better": True, "data": "synthetic", "dtype": "f64+f32",
-           "link_updates_per_s": e.n_links * B * K / wall,
-           "config": {"workload": f"{args.network} x {B} envs, obs option3 ({env.n_obs} floats), {env.n_actions} action dims, "
-                                  f"agents {env.possible_agents}, actions resident in HBM (torch), obs/rewards left on device",
-                      "history": args.history,
+           "link_updates_per_s": L * B * K / wall,
+           # the whole env step against the roofline: SURVEY 8(d)'s 212 B per link-update (the observation / reward / action rows add
+           # 0.3 % on this network and are left out) over the device time of the timed region
+           "whole_step_frac": BYTES_PER_LINK_UPDATE * L * B / (dev_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "launches_per_env_step": 2,
+           "randomized": bool(randomized),
+           "config": {"workload": f"{network} x {B} envs, obs option3 ({env.n_obs} floats), {env.n_actions} action dims, "
+                                  f"agents {env.possible_agents}, actions resident in HBM (torch), obs/rewards left on device"
+                                  + (", every env with its own randomised scenario (reset(options={'randomize': True}))" if randomized else ""),
+                      "history": history,
                       "history_bytes": int(sum(e.history_rows(f) * (e.n_all if f < 4 else e.n_links) * ((B + 127) // 128 * 128) * (8 if f < 7 else 4)
                                                for f in range(13)))}}
-    print(json.dumps(out), flush=True)
+    if reset_s is not None:
+        out["randomized_reset_s"] = reset_s
     env.close()
+    return out
+
+
+def bench_rl(args):
+    print(json.dumps(measure_rl(args.network, args.replicas, args.steps, args.warmup, args.history, args.randomize)), flush=True)
 
 
 def spawn_ranks(args, argv):
@@ -266,7 +292,12 @@ def measure(args, network, dist, rank, local_rank, world):
     from pednstream_amd import NetworkEnvGenerator
     from pednstream_amd.ensemble import shard
 
-    R = args.replicas                                          # weak scaling: R replicas on every GPU
+    if args.total_replicas:                                    # strong scaling: the ensemble is fixed, every GPU owns total / N replicas
+        if args.total_replicas % world:
+            raise SystemExit(f"--total-replicas {args.total_replicas} is not a multiple of --gpus {world}")
+        R = args.total_replicas // world
+    else:
+        R = args.replicas                                      # weak scaling: R replicas on every GPU
     offset, count = shard(R * world, world, rank)              # contiguous block of global replica ids
     assert count == R
     gen = NetworkEnvGenerator(os.path.join(ROOT, "data"))
@@ -375,23 +406,45 @@ def measure(args, network, dist, rank, local_rank, world):
     # time the machine spends on one step of all replicas: one chain -> the sum of its launches (gaps excluded); two chains ->
     # their launches overlap, so the device time of the timed region (HIP events around it) per step
     step_ms = node_ms + link_ms + tf_ms if chains == 1 else dev_ms / args.steps
-    achieved = node_bytes / (node_ms * 1e-3) / 1e9
+    achieved_alg = node_bytes / (node_ms * 1e-3) / 1e9
     traffic, traffic_src = measured_traffic("node_kernel", network, R)     # per launch, measured under this same plan
+    live = traffic is not None and traffic_src.startswith("live")
+    # the second launch's memory-side bytes, for the working set of a step
+    traffic2 = None
+    for k2 in ("link_turn_kernel", "link_kernel"):
+        t2, _ = measured_traffic(k2, network, R)
+        if t2 is not None:
+            traffic2 = t2
+            break
+    # `achieved` / `frac`: bytes the memory side MOVED for the launch (FETCH_SIZE + WRITE_SIZE) over its duration when the PMC passes
+    # of this run succeeded -- the kernel moves fewer bytes than the contract counts (shared widths and static fractions are scalar
+    # loads, cumulative_*[t-1] is reused), so the contract figure over the same duration would overstate what the memory system did;
+    # that figure stays beside it as `achieved_algorithmic` / `frac_algorithmic`.  Without live counters both pairs are the contract's.
+    achieved = traffic / (node_ms * 1e-3) / 1e9 if live else achieved_alg
+    working_set = None if traffic is None or traffic2 is None else (traffic + traffic2) * chains
     mdl = e.model
     n_dyn_turns = int(np.diff(mdl["node_turn_ptr"])[np.asarray(mdl["node_dyn"]) > 0].sum())     # +8 B each per replica
     out = {
         "metric": "link-updates/sec (links x replicas x steps/sec)", "value": total_lu / wall, "unit": "link-updates/s",
         "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64+f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.total_replicas else "weak", "vs_baseline": None, "dtype": "f64+f32", "data": "synthetic",
         "config": {"workload": f"{network} network ({L} links, {len(net.nodes)} nodes, T={T}) x {R} replicas per GPU, "
                                f"{'full-record' if args.history == 'full' else 'recent-history'} mode, per-replica Poisson demand and Philox keys",
-                   "replicas_per_gpu": R, "links": L, "parallelism": f"replica-sharded x{world}, no step-path collective"},
+                   "replicas_per_gpu": R, "replicas_total": R * world, "links": L,
+                   "parallelism": f"replica-sharded x{world}, no step-path collective"},
         "device_ms_per_step": dev_ms / args.steps,
         "roofline": {"bound": "hbm", "kernel": "node_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
+                     "basis": ("bytes moved: rocprofv3 FETCH_SIZE + WRITE_SIZE of this run per launch / the launch's duration" if live else
+                               "algorithmic bytes per launch / the launch's duration (no live counter passes in this run)"),
+                     "achieved_algorithmic": achieved_alg, "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "frac_counter": None if traffic is None else traffic / (node_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic_bytes_per_link_update": None if traffic is None else traffic * chains / (L * R),
+                     # what one step touches, and whether "hbm" means HBM: a step whose working set fits the 256 MB Infinity Cache is
+                     # served from it between the launches (FETCH_SIZE counts those hits too)
+                     "working_set_bytes_per_step": working_set,
+                     "fits_infinity_cache": None if working_set is None else bool(working_set < 256e6),
                      "concurrent_chains": chains, "replicas_per_launch": R // chains,
                      "note": ("run() launches the two halves of the replicas as two chains on two streams: `achieved` / `frac` are per launch "
                               "(R / 2 replicas) while the other chain's launches share the machine; the machine-level figure is whole_step_frac"
@@ -399,8 +452,10 @@ def measure(args, network, dist, rank, local_rank, world):
                      "algorithmic_bytes_per_launch": node_bytes, "algorithmic_bytes_per_link_update": NODE_KERNEL_BYTES,
                      "avg_launch_ms": float(node_ms),
                      "other_kernels_ms": {"link_kernel(+turn_frac of t+1)": float(link_ms), "turn_frac_kernel(stand-alone)": float(tf_ms)},
+                     "second_launch_traffic": traffic2,
                      "whole_step_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
                      "whole_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "whole_step_frac_counter": None if working_set is None else working_set / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "whole_step_basis": "sum of the step's launch durations" if chains == 1 else "device time of the timed region per step (two overlapping chains)",
                      "whole_step_frac_wall": step_bytes / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
                      "whole_step_bytes_per_link_update": BYTES_PER_LINK_UPDATE,
@@ -429,6 +484,9 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--rng-mode", default="philox", choices=["philox", "meanfield"], help="diagnostic: meanfield removes the RNG work")
     ap.add_argument("--rl", action="store_true", help="config #5 instead: batched RL env step, env-steps/s")
+    ap.add_argument("--randomize", action="store_true", help="with --rl: reset(options={'randomize': True}) first (per-replica scenarios)")
+    ap.add_argument("--total-replicas", type=int, default=0, help="strong scaling: this many replicas in all, total / N per GPU "
+                    "(BASELINE config #4: --total-replicas 4096; its weak-scaling shape is --replicas 512)")
     ap.add_argument("--history", default="full", choices=["full", "recent"], help="full: the reference's footprint (the headline mode); "
                     "recent: rings for everything the recurrence does not look far back into (include/pedn.h PEDN_HIST_RECENT)")
     args = ap.parse_args()
@@ -441,7 +499,8 @@ def main():
         if args.gpus > 1:             # nothing has touched the GPU yet: the ranks run in a child, this process only relays its exit code
             raise SystemExit(spawn_ranks(args, sys.argv[1:]))
         if args.gpus == 1 and not args.no_extra and not args.rl and not args.no_live_traffic:
-            live_traffic([args.network] + (["delft"] if args.network == "melbourne" and args.replicas == 1024 else []), args.replicas, args.history)
+            headline = args.network == "melbourne" and args.replicas == 1024 and not args.total_replicas
+            live_traffic([(args.network, args.total_replicas or args.replicas)] + ([("delft", 1024), ("melbourne", 4096)] if headline else []), args.history)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -471,14 +530,26 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flatten_network(net), net, origins, args.network)
     net.close()
-    if rank == 0 and world == 1 and not args.no_extra and args.network == "melbourne" and args.replicas == 1024:
+    if rank == 0 and world == 1 and not args.no_extra and args.network == "melbourne" and args.replicas == 1024 and not args.total_replicas:
+        import copy
+        keep = ("value", "unit", "ms_per_step", "device_ms_per_step", "config", "roofline")
         # BASELINE config #3 (the network BASELINE.json names for the rocprof roofline), same engine, same run
         ex, net3, origins3 = measure(args, "delft", None, 0, local_rank, 1)
         if not args.no_cpu_baseline:
             ex["cpu_baseline"] = cpu_baseline(flatten_network(net3), net3, origins3, "delft", seconds_target=4.0)
         net3.close()
-        out["extra"] = {"config3_delft_x1024": {k: ex[k] for k in ("value", "unit", "ms_per_step", "device_ms_per_step", "config", "roofline")
-                                                 + (("cpu_baseline",) if "cpu_baseline" in ex else ())}}
+        out["extra"] = {"config3_delft_x1024": {k: ex[k] for k in keep + (("cpu_baseline",) if "cpu_baseline" in ex else ())}}
+        # the same headline network with a working set beyond the 256 MB Infinity Cache (4096 replicas: the per-GPU shape of nothing in
+        # BASELINE, but the point where "hbm" means HBM), with its own counter passes
+        a4 = copy.copy(args)
+        a4.replicas, a4.steps, a4.warmup, a4.no_extra = 4096, min(args.steps, 120), min(args.warmup, 30), True
+        ex4, net4, _ = measure(a4, "melbourne", None, 0, local_rank, 1)
+        net4.close()
+        out["extra"]["hbm_proper_melbourne_x4096"] = {k: ex4[k] for k in keep}
+        # BASELINE config #5: the batched RL env step on 45_intersections x 2048 envs, shared scenario and per-env randomised scenarios
+        out["extra"]["config5_rl_45int_x2048"] = {
+            "plain": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=False),
+            "randomized": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=True)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -65,6 +65,7 @@ struct pedn_sim {
   int32_t *d_fft_r = nullptr, *d_tausw_r = nullptr;
   float* d_tt0_r = nullptr;  // links whose widths the RL action kernel writes per replica: never uniform
   int n_pair = 0, n_up = 0, n_over = 0;
+  int n_tf_heavy_quads = 0;  // leading workgroups of turn_frac_body with long chains (more than PEDN_TF_HEAVY_GROUPS softmax groups in a row)
   long step_epoch = 1;  // counts launched steps; h_tf_set_epoch[node] == step_epoch: fractions imposed since the last step
   std::vector<long> h_tf_set_epoch;
   int rows64[7], rows32[6];  // history rows of every field (T+1, or the size of its ring in recent-history mode)
@@ -343,11 +344,13 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
   {
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; return fail(nullptr, PEDN_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-    hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
-    hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
-    hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
-    hipEventCreate(&s->ev0);
-    hipEventCreate(&s->ev1);
+    // a null stream2 would be the legacy default stream (it synchronises with everything): every handle is checked
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    if (e != hipSuccess) { pedn_destroy(s); return fail(nullptr, PEDN_E_DEVICE, std::string("second stream / events: ") + hipGetErrorString(e)); }
   }
   // ---- memory budget
   {
@@ -547,6 +550,14 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     }
     gwords.resize(gwords.size() + 8 * 32, 0);  // turn_frac_body reads a chunk of four records ahead; padding has n = 0
     rows = packed;
+    {  // the workgroups (quads of rows, heaviest first) whose dependent chains are longer than a link-update workgroup lasts: inside
+       // link_turn_kernel they are dispatched in front of the link update, the short ones behind it (launch_step)
+      int heavy_groups = 2;
+      if (const char* d = getenv("PEDN_TF_HEAVY_GROUPS")) heavy_groups = atoi(d);
+      s->n_tf_heavy_quads = 0;
+      for (size_t q = 0; q * 4 < rows.size(); ++q)
+        if (rows[q * 4].groups > heavy_groups) s->n_tf_heavy_quads = (int)q + 1;
+    }
     v.n_multi = n_multi;
     v.n_trow = (int)rows.size();
     s->n_over = n_over;
@@ -1009,7 +1020,9 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   DevView vn = v;                 // node_kernel's view: with the action rows when it applies the gater actions itself
   vn.rl_actions = fold_actions;
   const unsigned rgroups = (unsigned)(v.subRS / 64);
-  const bool groups = v.n_trow > 0, fused = groups && s->fuse_tp;
+  // the turning fractions of t + 1 ride in the launch behind node_kernel(t) -- except behind the last step of the horizon, where
+  // pair_pod / turn_tab have no row T + 1 to read (they hold T + 1 rows, 0..T) and nothing would consume the result
+  const bool groups = v.n_trow > 0, fused = groups && s->fuse_tp && t + 1 <= v.T1 - 1;
   const bool obs_fused = observe >= 0 && s->rl_ready && s->fuse_obs;
   auto launch = [&](auto kernel, dim3 grid, dim3 block, int e, auto... args) {
     if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev[e], ev[e + 1], 0, args...);
@@ -1024,22 +1037,22 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   if (ev) hipExtLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, ev[2], ev[3], 0, vn, t);
   else hipLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, vn, t);
   // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
-  const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0) ? 2 : 1;
+  const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0 && !obs_fused) ? 2 : 1;   // (the diagnostic NS = 2 has no OBS instantiation)
   const unsigned nlb = v.n_pairs_corr > 0 && !s->fuse_link ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.subRS : v.subRS / (2 * ns)) + 255) / 256) : 0u;
   s->second_launch = 1;
   if (fused || obs_fused) {
     const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;
+    const unsigned nth = fused ? (unsigned)s->n_tf_heavy_quads * rgroups : 0u;  // of which in front of the link update
     const unsigned nob = obs_fused ? (unsigned)s->rl.n_agents * rgroups : 0u;  // one block per (agent, 64 replicas)
     RlView q = s->rl;
     if (!obs_fused) q.n_agents = 0;
     const int acc = observe > 0 ? 1 : 0;
     const dim3 grid(nlb + ntb + nob), block(256);
     // instantiation by (per-replica parameters, observations in the launch, segments per lane, recent-history mode)
-#define PEDN_LT(PR_, OBS_, NS_) do { if (v.hist) launch(link_turn_kernel<PR_, OBS_, NS_, true>, grid, block, 4, v, t, nlb, ntb, q, acc); \
-                                     else launch(link_turn_kernel<PR_, OBS_, NS_, false>, grid, block, 4, v, t, nlb, ntb, q, acc); } while (0)
+#define PEDN_LT(PR_, OBS_, NS_) do { if (v.hist) launch(link_turn_kernel<PR_, OBS_, NS_, true>, grid, block, 4, v, t, nlb, ntb, nth, q, acc); \
+                                     else launch(link_turn_kernel<PR_, OBS_, NS_, false>, grid, block, 4, v, t, nlb, ntb, nth, q, acc); } while (0)
     if (obs_fused) {
       if (v.pr) PEDN_LT(true, true, 1);
-      else if (ns == 2) PEDN_LT(false, true, 2);
       else PEDN_LT(false, true, 1);
     } else {
       if (v.pr) PEDN_LT(true, false, 1);
@@ -1096,6 +1109,19 @@ static bool two_chains(const pedn_sim* s, int t0, int t1) {
   return s->two_streams && t1 - t0 >= 8 && s->v.RS % 256 == 0;
 }
 
+// Join of the two chains of launches: the engine's stream waits for everything enqueued on stream2.  If the event path fails the
+// streams are drained instead, so that no call ever returns with work on stream2 that the engine's stream does not order.
+static int join_chains(pedn_sim* s) {
+  hipError_t e = hipEventRecord(s->ev_join, s->stream2);
+  if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->ev_join, 0);
+  if (e != hipSuccess) {
+    hipStreamSynchronize(s->stream2);
+    hipStreamSynchronize(s->stream);
+    return fail(s, PEDN_E_DEVICE, std::string("joining the two chains of launches: ") + hipGetErrorString(e));
+  }
+  return PEDN_OK;
+}
+
 int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (t0 < 1 || t1 > s->v.T1 || t0 > t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
@@ -1111,8 +1137,8 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
       launch_step(s, t, nullptr, -1, nullptr, nullptr, 0);
       launch_step(s, t, nullptr, -1, nullptr, nullptr, 1);
     }
-    HIP_TRY(s, hipEventRecord(s->ev_join, s->stream2));
-    HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
+    const int rc = join_chains(s);
+    if (rc != PEDN_OK) return rc;
   } else {
     for (int t = t0; t < t1; ++t) launch_step(s, t);
   }
@@ -1158,8 +1184,8 @@ int pedn_profile_run(pedn_sim* s, int32_t t0, int32_t t1, float ms[3], int32_t* 
       second[k] = s->second_launch;
     }
   if (two) {
-    HIP_TRY(s, hipEventRecord(s->ev_join, s->stream2));
-    HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
+    const int rc = join_chains(s);
+    if (rc != PEDN_OK) return rc;
   }
   HIP_TRY(s, hipGetLastError());
   HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -1207,7 +1233,8 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
     return fail(s, PEDN_E_ARG, "read range out of bounds");
   const int rows = field < 7 ? s->rows64[field] : s->rows32[field - 7], mask = field < 7 ? v.m64[field] : v.m32[field - 7];
   if (rows < v.T1) {  // recent-history mode: only the newest `rows` time indices of this field exist
-    const int newest = std::max(s->last_t, 0);
+    // sending_flow / receiving_flow of step t are entries t - 1 (node.py:206, link.py:367): their newest entry is one behind
+    const int newest = std::max((field == F_S || field == F_R) ? s->last_t - 1 : s->last_t, 0);
     if (t1 - 1 > newest || t0 <= newest - rows)
       return fail(s, PEDN_E_ARG, "time index outside the field's ring (recent-history mode keeps the last " + std::to_string(rows) +
                                  " entries of this field; the newest is " + std::to_string(newest) + ")");

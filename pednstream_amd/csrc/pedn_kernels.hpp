@@ -213,10 +213,12 @@ __device__ __forceinline__ int as_vector(int x) {
 // FUSED: the wave runs inside link_turn_kernel next to the link update of step t-1, which has not stored
 // num_pedestrians[t-1] / density[t-1] yet -- they are recomputed here from [t-2] and the flows of t-1 with the arithmetic of
 // the link update (link.py:133-136), so the parts of that launch do not depend on each other.
+// lds: PEDN_TF_LDS_DOUBLES doubles of the workgroup's LDS (the kernel owns the buffer: the parts of link_turn_kernel share one)
+#define PEDN_TF_LDS_DOUBLES ((PEDN_TF_LDS_ROWS + PEDN_MAX_DEGREE - 1) * 64)
 template <bool PR, bool FUSED, bool HIST>
-__device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned block) {
-  __shared__ double sP[PEDN_TF_LDS_ROWS * 64];
-  __shared__ double sAcc[(PEDN_MAX_DEGREE - 1) * 64];  // coop rows: the turns' sums on their way to wave 0
+__device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned block, double* lds) {
+  double* const sP = lds;                               // [PEDN_TF_LDS_ROWS][64] probabilities of the workgroup's rows
+  double* const sAcc = lds + PEDN_TF_LDS_ROWS * 64;     // [PEDN_MAX_DEGREE - 1][64] coop rows: the turns' sums on their way to wave 0
   constexpr int NE = PEDN_MAX_DEGREE - 1;
   const int RS = v.RS;
   const unsigned rgroups = (unsigned)(v.subRS / 64);
@@ -518,7 +520,8 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
 // stand-alone launch: first step of an episode, or a step that does not follow the previous one
 template <bool PR, bool HIST>
 __global__ __launch_bounds__(256) void turn_frac_kernel(DevView v, int t) {
-  turn_frac_body<PR, false, HIST>(v, t, blockIdx.x);
+  __shared__ double lds[PEDN_TF_LDS_DOUBLES];
+  turn_frac_body<PR, false, HIST>(v, t, blockIdx.x, lds);
 }
 
 // RegularNode.solve('optimal') (node.py:249-271) for 64 replicas of one node, one LP per lane: dense primal simplex on the
@@ -608,10 +611,9 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // guards the budget: one more live register in the wrong place turns the scalar spills into 16 vector spills (+11 us).
 // LP: the node model is the linear programme of assign_flows_type 'optimal' instead of the classic proportional rule.
 // FUSE: the link update of t happens in this launch too.  A corridor's state needs inflow[t] / outflow[t] of both directions,
-// i.e. the results of the two slot waves at its two ends, which run in different workgroups: each wave publishes its two flows
-// write-through (sc1), waits for its stores, then adds to the corridor's arrival counter (agent scope); the wave whose add comes
-// second loads the other wave's two flows (sc1 loads, they bypass this CU's L1) and updates both directions.  No wave waits for
-// another.  The counters are never reset inside a step: every launch adds exactly two, the parity tells first from second.
+// i.e. the results of the two slot waves at its two ends, which run in different workgroups: each wave stores its two flows,
+// releases them at agent scope, then adds to the corridor's arrival counter; the wave whose add comes second acquires at agent
+// scope, loads the other wave's two flows and updates both directions.  No wave waits for another.  The counters are never reset inside a step: every launch adds exactly two, the parity tells first from second.
 template <bool HIST>
 __device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& Pa, const LinkP& Pb, int a, int b, int t, int r,
                                                 double da, double db, float pa, float pb);
@@ -810,16 +812,19 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     rowp(v.f64[F_CI], R64(F_CI, t), lout, Lall, RS, r0)[lane] = ci_prev + qi;
     if (fl) atomicOr(&v.flags[r], fl);
     if (FUSE && lin < L) {
-      __hip_atomic_store(p_out, qo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
-      __hip_atomic_store(p_in, qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's flows have left the chip's caches before it signals
+      // hand-off by the memory model, not by ISA details: plain stores, a release fence at agent scope by every lane (their stores
+      // are written back from this XCD's L2), the arrival counted with an acq_rel add, and an agent-scope acquire fence in the
+      // wave that finds the other end's flows published (its L1 / L2 lines of them are invalidated before the loads)
+      *p_out = qo;
+      *p_in = qi;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       int arrived = 0;
-      if (lane == 0) arrived = __hip_atomic_fetch_add(&v.arrive[(size_t)corr * (size_t)(RS / 64) + (size_t)(r0 >> 6)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) arrived = __hip_atomic_fetch_add(&v.arrive[(size_t)corr * (size_t)(RS / 64) + (size_t)(r0 >> 6)], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       arrived = __builtin_amdgcn_readfirstlane(arrived);
       if (arrived & 1) {  // the other end of the corridor has published: Network.update_link_states for both directions
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double in_lin = __hip_atomic_load(rowp(v.f64[F_IN], R64(F_IN, t), lin, Lall, RS, r0) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double out_lout = __hip_atomic_load(rowp(v.f64[F_OUT], R64(F_OUT, t), lout, Lall, RS, r0) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const double in_lin = rowp(v.f64[F_IN], R64(F_IN, t), lin, Lall, RS, r0)[lane];
+        const double out_lout = rowp(v.f64[F_OUT], R64(F_OUT, t), lout, Lall, RS, r0)[lane];
         const LinkP Pa = lane_params<PR>(v, W.Pout, lout, r), Pb = lane_params<PR>(v, W.Pin, lin, r);
         link_update_one<HIST>(v, Pa, Pb, lout, lin, t, r, qi - out_lout, in_lin - qo, np_out, np_in);
       }
@@ -1064,9 +1069,13 @@ __global__ void rl_apply_kernel(DevView v, RlView q) {
 // reference).  FUSED: the block runs inside link_turn_kernel next to the link update of the same step, which has not stored
 // travel time, speed and density of step t yet: they are recomputed for the agent's links with the link update's own
 // arithmetic (speed_calc with the same Philox key), so the parts of that launch stay independent.
+// lds: 3 * PEDN_MAX_DEGREE * 64 floats of the workgroup's LDS
+#define PEDN_OBS_LDS_FLOATS (3 * PEDN_MAX_DEGREE * 64)
 template <bool FUSED, bool HIST>
-__device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& q, int t, int accumulate, unsigned block) {
-  __shared__ float sT[PEDN_MAX_DEGREE][64], sD[PEDN_MAX_DEGREE][64], sKc[PEDN_MAX_DEGREE][64];
+__device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& q, int t, int accumulate, unsigned block, float* lds) {
+  float (*const sT)[64] = reinterpret_cast<float (*)[64]>(lds);
+  float (*const sD)[64] = reinterpret_cast<float (*)[64]>(lds + PEDN_MAX_DEGREE * 64);
+  float (*const sKc)[64] = reinterpret_cast<float (*)[64]>(lds + 2 * PEDN_MAX_DEGREE * 64);
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
@@ -1165,28 +1174,39 @@ __device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& 
 
 template <bool HIST>
 __global__ __launch_bounds__(256) void rl_observe_kernel(DevView v, RlView q, int t, int accumulate) {
-  rl_observe_body<false, HIST>(v, q, t, accumulate, blockIdx.x);
+  __shared__ float lds[PEDN_OBS_LDS_FLOATS];
+  rl_observe_body<false, HIST>(v, q, t, accumulate, blockIdx.x, lds);
 }
 
-// ONE launch after node_kernel(t) for everything that only reads what node_kernel(t) and earlier launches wrote:
-//   blocks [0, n_tp)                the turning fractions of step t+1 (models with dynamic nodes)
-//   blocks [n_tp, n_tp + n_link)    the link update of step t
-//   the remaining blocks            observations and rewards of step t for the batched RL env (q.n_agents > 0)
-// The parts are independent (the second and third re-derive what the first is about to store), so they run side by side;
-// as separate launches each of them cost 5-9 us, most of it the fixed cost of a launch.
+// ONE launch after node_kernel(t) for everything that only reads what node_kernel(t) and earlier launches wrote, in dispatch order:
+//   blocks [0, n_tp_heavy)                      turning fractions of step t+1, the rows with long chains of softmax groups
+//   the next n_link_blocks blocks               the link update of step t
+//   the next n_tp_blocks - n_tp_heavy blocks    turning fractions of step t+1, the short rows
+//   the remaining blocks                        observations and rewards of step t for the batched RL env (q.n_agents > 0)
+// The parts are independent (the second and fourth re-derive what the others are about to store), so they run side by side;
+// as separate launches each of them cost 5-9 us, most of it the fixed cost of a launch.  Longest first: a row with eight softmax
+// groups is ~11 us of dependent binary64 arithmetic, a link-update workgroup lasts 5-6 us, a row with one or two groups 4-5 us.  The
+// launch is more workgroups than the machine holds at this kernel's register budget (4 per CU), so what is dispatched last starts
+// when the first workgroups retire: with every turning-fraction workgroup in front, a third of the link update started only after
+// the short rows had finished and ended long after the long rows (delft x 1024: 20.8 us for 12 us of critical path).
 // (OBS = false: the instantiation ordinary stepping uses carries neither the LDS nor the registers of the third part)
 template <bool PR, bool OBS, int NS, bool HIST>
-__global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, RlView q, int accumulate) {
-  // the turning-fraction workgroups come first in dispatch order: theirs are the long dependent chains of the launch (the
-  // heaviest rows lead), the link update behind them is bound by memory throughput and fills the machine around them
-  if (blockIdx.x < n_tp_blocks) {
-    turn_frac_body<PR, true, HIST>(v, t + 1, blockIdx.x);
-  } else if (blockIdx.x < n_tp_blocks + n_link_blocks) {
-    const size_t gid = (size_t)(blockIdx.x - n_tp_blocks) * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, unsigned n_tp_heavy, RlView q,
+                                                           int accumulate) {
+  // one LDS buffer for whichever part this workgroup is (the observation part needs 6 KB of the turning fractions' 35.5 KB)
+  __shared__ double lds[PEDN_TF_LDS_DOUBLES];
+  static_assert(sizeof(double) * PEDN_TF_LDS_DOUBLES >= sizeof(float) * PEDN_OBS_LDS_FLOATS, "observation rows must fit");
+  // role of this workgroup (one call site per part: each is inlined once)
+  const unsigned b = blockIdx.x;
+  const bool is_tp = b < n_tp_heavy || (b >= n_tp_heavy + n_link_blocks && b < n_tp_blocks + n_link_blocks);
+  if (is_tp) {
+    turn_frac_body<PR, true, HIST>(v, t + 1, b < n_tp_heavy ? b : b - n_link_blocks, lds);
+  } else if (b < n_tp_heavy + n_link_blocks) {
+    const size_t gid = (size_t)(b - n_tp_heavy) * blockDim.x + threadIdx.x;
     if (PR) link_pr_body<HIST>(v, t, gid);
     else link_body<NS, HIST>(v, t, gid);
   } else if (OBS) {
-    rl_observe_body<true, HIST>(v, q, t, accumulate, blockIdx.x - n_link_blocks - n_tp_blocks);
+    rl_observe_body<true, HIST>(v, q, t, accumulate, b - n_link_blocks - n_tp_blocks, reinterpret_cast<float*>(lds));
   }
 }
 

@@ -584,7 +584,9 @@ class Network:
                 self._col_cache.clear()
             rows = eng.history_rows(fid)
             if rows < self.simulation_steps + 1:      # recent-history mode: the entries still in the ring, NaN elsewhere
-                hi = max(self.current_step, 0)
+                # sending_flow / receiving_flow of step t are entries t - 1: their newest entry is one behind (in full-record
+                # mode entry t still holds its initial -1 at that point; a ring slot would hold the value of t - rows)
+                hi = max(self.current_step - 1 if fid in (LINK_FIELDS["sending_flow"][0], LINK_FIELDS["receiving_flow"][0]) else self.current_step, 0)
                 lo = max(0, hi - rows + 1)
                 col = np.full(self.simulation_steps + 1, np.nan, dtype=LINK_DTYPES[fid])
                 col[lo:hi + 1] = eng.read_block(fid, lo, hi + 1, link_index, link_index + 1, self._replica_index(),

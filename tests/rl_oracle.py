@@ -11,9 +11,14 @@ FPL = {"option1": 3, "option2": 4, "option3": 5, "option4": 2, "option5": 7}
 
 
 class RlOracle:
-    def __init__(self, net, model, spec, obs_mode, normalize, action_gap, seed=0, replica=0, reward_mode="reference"):
-        """spec: list of {"id", "type", "links": [link ids "u_v"]} in agent order."""
+    def __init__(self, net, model, spec, obs_mode, normalize, action_gap, seed=0, replica=0, reward_mode="reference",
+                 link_kc=None, link_kj=None):
+        """spec: list of {"id", "type", "links": [link ids "u_v"]} in agent order.  link_kc / link_kj: k_critical / k_jam per
+        link of THIS replica when the batch carries per-replica scenarios (the reward and option4 read them, pz_pednet_env.py:569,
+        builders.py:157); default: the network's own."""
         self.net, self.model = net, model
+        self.kc = None if link_kc is None else np.asarray(link_kc, dtype=np.float64)
+        self.kj = None if link_kj is None else np.asarray(link_kj, dtype=np.float64)
         self.o = od.Oracle(model, seed=seed, replica=replica)
         self.obs_mode, self.normalize, self.gap, self.reward_mode = obs_mode, normalize, action_gap, reward_mode
         self.links = list(net.links.values())
@@ -95,13 +100,13 @@ class RlOracle:
                 feats = {"option1": [f["inflow"][l.index, t], f["outflow"][r.index, t], gate],
                          "option2": [f["inflow"][l.index, t], f["outflow"][r.index, t], dens, gate],
                          "option3": [f["inflow"][l.index, t], f["outflow"][l.index, t], f["inflow"][r.index, t], f["outflow"][r.index, t], gate],
-                         "option4": [dens / l.k_jam, gate],
+                         "option4": [dens / (l.k_jam if self.kj is None else float(self.kj[l.index])), gate],
                          "option5": [f["inflow"][l.index, t], f["outflow"][l.index, t], f["inflow"][r.index, t], f["outflow"][r.index, t],
                                      f["speed"][l.index, t], dens, gate]}[self.obs_mode]
                 x[i * fpl:(i + 1) * fpl] = feats
                 lr -= f["travel_time"][l.index, t] + f["travel_time"][r.index, t]
                 if dens > 4:
-                    lr -= 10 * (dens - l.k_critical)
+                    lr -= 10 * (dens - (l.k_critical if self.kc is None else float(self.kc[l.index])))
                 dens_all.append(dens)
             if self.normalize:
                 for i in range(len(links)):

@@ -92,3 +92,37 @@ def test_two_ranks_on_one_gpu_gather_device_tensors_and_match_the_single_rank_ru
         last = ref[-1][0].astype(np.float64)
         assert np.allclose(moments[0], last.mean(axis=0), rtol=1e-12, atol=1e-12) and np.allclose(moments[1], last.var(axis=0), rtol=1e-9, atol=1e-9)
     assert not np.array_equal(ref[-1][0][0], ref[-1][0][40])          # envs really differ
+
+
+def test_bench_under_the_launcher_runs_the_rccl_branch_once():
+    """The driver's N > 1 runs go through `python -m torch.distributed.run ... bench.py --gpus N`: backend "nccl" (= RCCL) with
+    device_id, barrier + torch.cuda.synchronize around the timed region, cuda-tensor all_reduce of the wall time and of the rank
+    count.  One rank under the launcher executes exactly that code on hardware (two ranks need two GPUs: RCCL refuses to share
+    a device); its line must agree with a plain N = 1 run of the same short command.  Also the strong-scaling shape."""
+    import json
+    import subprocess
+
+    pytest.importorskip("torch")
+    bench = os.path.join(ROOT, "bench.py")
+    short = ["--gpus", "1", "--steps", "60", "--warmup", "20", "--no-extra", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+
+    def line(cmd):
+        out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(rows) == 1, out.stdout[-2000:]
+        return rows[0]
+
+    launched = line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                     "--master-port", str(_free_port()), bench] + short)
+    plain = line([sys.executable, bench] + short)
+    assert launched["ranks_seen"] == 1 and launched["n_gpus"] == 1 and launched["scaling"] == "weak"
+    # the device time per step is the comparable quantity (the wall clock of 60 steps carries the barrier and the reductions)
+    assert abs(launched["device_ms_per_step"] / plain["device_ms_per_step"] - 1) < 0.10, (launched["device_ms_per_step"], plain["device_ms_per_step"])
+    assert abs(launched["value"] / plain["value"] - 1) < 0.25, (launched["value"], plain["value"])
+    strong = line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), bench, "--total-replicas", "512"] + short)
+    assert strong["scaling"] == "strong" and strong["config"]["replicas_per_gpu"] == 512 and strong["config"]["replicas_total"] == 512
