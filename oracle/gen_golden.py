@@ -49,7 +49,7 @@ def save(case, static, state, extras, info):
 
 
 def scenario_case(case, name, steps=None, seed=0, replica=0, mode="philox", np_seed=20261003, mutations=None,
-                  demand_override=None):
+                  demand_override=None, create_kwargs=None, info_extra=None):
     muts = mutations or []
 
     def mutate(net, t):
@@ -66,19 +66,21 @@ def scenario_case(case, name, steps=None, seed=0, replica=0, mode="philox", np_s
 
     net, static, state, extras = rh.run_reference(name, steps=steps, seed=seed, replica=replica, mode=mode,
                                                   mutate=mutate if muts else None, np_seed=np_seed, record_tf=True,
-                                                  demand_override=demand_override)
+                                                  demand_override=demand_override, create_kwargs=create_kwargs)
     extras["tf"] = tf_matrix(net, extras)
     save(case, static, state, extras, {"scenario": name, "seed": seed, "replica": replica, "mode": mode,
-                                       "np_seed": np_seed, "mutations": muts})
+                                       "np_seed": np_seed, "mutations": muts, **(info_extra or {})})
     return net
 
 
 def direct_case(case, adj, params, origin_nodes, destination_nodes=(), steps=None, seed=0, replica=0, tf_nodes=None,
-                tf_values=None, mutations=None, np_seed=20261003):
+                tf_values=None, mutations=None, np_seed=20261003, demand_pattern=None):
+    """demand_pattern: custom demand callables handed to Network(..., demand_pattern=[...]) (network.py:88-93); the fixture
+    records their names, the tests pass the same callables (tests/demand_callables.py) to this repository's Network."""
     ref = rh.load_reference()
     np.random.seed(np_seed)
     net = ref["network"].Network(np.array(adj), params, origin_nodes=list(origin_nodes),
-                                 destination_nodes=list(destination_nodes))
+                                 destination_nodes=list(destination_nodes), demand_pattern=demand_pattern)
     if tf_nodes:
         net.update_turning_fractions_per_node(node_ids=list(tf_nodes), new_turning_fractions=np.array(tf_values))
     muts = mutations or []
@@ -97,7 +99,8 @@ def direct_case(case, adj, params, origin_nodes, destination_nodes=(), steps=Non
                                        "origin_nodes": list(origin_nodes), "destination_nodes": list(destination_nodes),
                                        "tf_nodes": list(tf_nodes or []), "tf_values": np.array(tf_values if tf_values is not None else []).tolist(),
                                        "seed": seed, "replica": replica, "mode": "philox", "np_seed": np_seed,
-                                       "mutations": muts})
+                                       "mutations": muts,
+                                       **({"demand_callables": [f.__name__ for f in demand_pattern]} if demand_pattern else {})})
 
 
 def step_digests(arr):
@@ -517,6 +520,21 @@ for _r in range(4):
         f"nine_replica{r}", "nine_intersections", steps=160, seed=0, replica=r,
         demand_override={0: replica_demand(500, 3 * r + 0), 8: replica_demand(500, 3 * r + 1),
                          2: replica_demand(500, 3 * r + 2, peak=50.0)}))
+
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import demand_callables as dc  # noqa: E402
+
+CASES.update({   # custom demand callables through the boundary (examples/spike.py:85-121, examples/Melbourne.py:36)
+    "spike_callable": lambda: direct_case("spike_callable", dc.SPIKE_ADJ, dc.spike_params(), [4], tf_nodes=[4], tf_values=[[1, 0, 0, 1, 0, 1]],
+                                          seed=6, replica=2, demand_pattern=[dc.plateau_pattern]),
+    "melbourne_callable": lambda: scenario_case(
+        "melbourne_callable", "melbourne", steps=170, seed=3, replica=1,
+        create_kwargs={"custom_demand_functions": [dc.make_table_demand(dc.MELBOURNE_TABLE)],
+                       "demand_params_overrides": {"origin_289": {"pattern": "node_demand_from_table"}}},
+        info_extra={"demand_callables": ["node_demand_from_table"],
+                    "demand_params_overrides": {"origin_289": {"pattern": "node_demand_from_table"}}}),
+})
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ struct pedn_sim {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int device = 0;
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
-  int node_waves = 8;  // register budget of node_kernel, see pedn_create
+  int node_waves = 8, node_waves_pr = 6;  // register budget of node_kernel (waves per SIMD) with shared / per-replica link parameters, see pedn_create
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
   int link_ns = 1;     // segments of 128 replicas per lane of the link update (launch_step); PEDN_LINK_NS=1|2
   int max_degree = 0;     // largest number of incident corridors of a node
@@ -646,8 +646,11 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     }
     // register budget of node_kernel: compiled for 8 waves per SIMD (64 VGPRs, a few SGPR spills) or for 6 (measured: delft 32.6
     // against 35.0 us, melbourne 25.8 against 27.1); PEDN_NODE_WAVES=6|8 overrides
+    // with per-replica link parameters (node_kernel<PR>: 28 more live vector registers) the budget of 8 waves costs 2..8 vector
+    // spills; at 6 waves there is none and the randomised RL step is 2 % faster (profiles/r03_pr_waves.txt)
     s->node_waves = 8;
-    if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = atoi(w) == 6 ? 6 : 8;
+    s->node_waves_pr = 6;
+    if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = s->node_waves_pr = atoi(w) == 6 ? 6 : 8;
     // The link update of t and the turning fractions of t+1 share one launch (both only read what node_kernel(t) and earlier
     // launches wrote); PEDN_FUSE_TP=0 gives the fractions a launch of their own in front of node_kernel(t+1).
     s->fuse_tp = 1;
@@ -997,7 +1000,7 @@ static node_kernel_fn node_kernel_for(const pedn_sim* s) {
                                      : (d6 ? node_kernel<PR_, W_, LP_, false, F_, 6> : node_kernel<PR_, W_, LP_, false, F_, 8>))
   if (s->node_lp) return s->v.pr ? PEDN_NK(true, 8, true, false) : PEDN_NK(false, 8, true, false);
   if (s->fuse_link) return s->v.pr ? PEDN_NK(true, 8, false, true) : PEDN_NK(false, 8, false, true);
-  if (s->v.pr) return s->node_waves == 8 ? PEDN_NK(true, 8, false, false) : PEDN_NK(true, 6, false, false);
+  if (s->v.pr) return s->node_waves_pr == 8 ? PEDN_NK(true, 8, false, false) : PEDN_NK(true, 6, false, false);
   return s->node_waves == 8 ? PEDN_NK(false, 8, false, false) : PEDN_NK(false, 6, false, false);
 #undef PEDN_NK
 }
@@ -1573,6 +1576,15 @@ extern "C" int pedn_debug_tphases(unsigned long long* out, int zero) {
   if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_tphase)) != hipSuccess) return -1;
   if (zero) return (int)hipMemset(dev, 0, sizeof(unsigned long long) * 4096 * 8);
   return (int)hipMemcpy(out, dev, sizeof(unsigned long long) * 4096 * 8, hipMemcpyDeviceToHost);
+}
+// [workgroup][role 0 long turning-fraction rows / 1 link update / 2 short rows / 3 observations, start, end, 0] of the LAST launch of
+// link_turn_kernel (zero = 1 clears)
+extern "C" int pedn_debug_lt_timeline(unsigned long long* out, int n_blocks, int zero) {
+  void* dev = nullptr;
+  if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_lt_time)) != hipSuccess) return -1;
+  if (zero) return (int)hipMemset(dev, 0, sizeof(unsigned long long) * PEDN_LT_BLOCKS * 4);
+  if (n_blocks > PEDN_LT_BLOCKS) n_blocks = PEDN_LT_BLOCKS;
+  return (int)hipMemcpy(out, dev, sizeof(unsigned long long) * (size_t)n_blocks * 4, hipMemcpyDeviceToHost);
 }
 extern "C" int pedn_debug_phases(unsigned long long* out, int zero) {
   const size_t n = (size_t)PEDN_PHASE_WAVES * 12;

@@ -27,6 +27,10 @@ __device__ unsigned long long g_phase[PEDN_PHASE_WAVES * 12];  // [wave of the g
 #define PH(i, dep) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) : "v"(dep) : "memory"); ph[i] = _t; } while (0)
 __device__ unsigned long long g_tphase[4096 * 8];  // turn_frac_body: [row][stamp] of replica group 0
 #define TPH(i, dep) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) : "v"(dep) : "memory"); tph[i] = _t; } while (0)
+// timeline of link_turn_kernel's workgroups (tools/lt_timeline.py): [workgroup][role, start, end of its last wave, 0] in ticks of the
+// constant 100 MHz clock (s_memrealtime, the same counter on every XCD)
+#define PEDN_LT_BLOCKS (1 << 15)
+__device__ unsigned long long g_lt_time[PEDN_LT_BLOCKS * 4];
 #else
 #define PH(i, dep)
 #define TPH(i, dep)
@@ -1199,6 +1203,12 @@ __global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, uns
   // role of this workgroup (one call site per part: each is inlined once)
   const unsigned b = blockIdx.x;
   const bool is_tp = b < n_tp_heavy || (b >= n_tp_heavy + n_link_blocks && b < n_tp_blocks + n_link_blocks);
+#ifdef PEDN_PHASE_PROFILE
+  if (threadIdx.x == 0 && b < PEDN_LT_BLOCKS) {
+    g_lt_time[b * 4] = is_tp ? (b < n_tp_heavy ? 0 : 2) : (b < n_tp_heavy + n_link_blocks ? 1 : 3);
+    g_lt_time[b * 4 + 1] = wall_clock64();
+  }
+#endif
   if (is_tp) {
     turn_frac_body<PR, true, HIST>(v, t + 1, b < n_tp_heavy ? b : b - n_link_blocks, lds);
   } else if (b < n_tp_heavy + n_link_blocks) {
@@ -1208,6 +1218,9 @@ __global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, uns
   } else if (OBS) {
     rl_observe_body<true, HIST>(v, q, t, accumulate, b - n_link_blocks - n_tp_blocks, reinterpret_cast<float*>(lds));
   }
+#ifdef PEDN_PHASE_PROFILE
+  if ((threadIdx.x & 63) == 0 && b < PEDN_LT_BLOCKS) atomicMax(&g_lt_time[b * 4 + 2], (unsigned long long)wall_clock64());
+#endif
 }
 
 // ---- state initialisation / host <-> device helpers ---------------------------------------------------------

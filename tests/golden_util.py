@@ -39,9 +39,35 @@ class Golden:
         return {int(k[len("static_demand_"):]): self.z[k] for k in self.z.files if k.startswith("static_demand_")}
 
 
+def _demand_callables(g: Golden):
+    """The callables a fixture names (tests/demand_callables.py), or None."""
+    names = g.info.get("demand_callables")
+    if not names:
+        return None
+    import demand_callables as dc
+
+    made = {"plateau_pattern": dc.plateau_pattern, "node_demand_from_table": dc.make_table_demand(dc.MELBOURNE_TABLE)}
+    return [made[n] for n in names]
+
+
 def build_network(g: Golden, **kw):
-    """This repository's Network for the golden's scenario, with the golden's demand arrays injected."""
+    """This repository's Network for the golden's scenario, with the golden's demand arrays injected -- except where the
+    fixture was built with custom demand callables: there the demand must come out of the callables, through the boundary."""
     np.random.seed(g.info["np_seed"])
+    fns = _demand_callables(g)
+    if fns is not None:
+        if g.info["scenario"] is not None:
+            net = NetworkEnvGenerator(DATA).create_network(g.info["scenario"], fns, demand_params_overrides=g.info.get("demand_params_overrides"),
+                                                           verbose=False, **kw)
+        else:
+            net = Network(np.array(g.info["adjacency"]), g.info["params"], origin_nodes=g.info["origin_nodes"],
+                          destination_nodes=g.info["destination_nodes"], demand_pattern=fns, verbose=False, **kw)
+            if g.info["tf_nodes"]:
+                net.update_turning_fractions_per_node(g.info["tf_nodes"], np.array(g.info["tf_values"]))
+        for nid, arr in g.demand().items():      # what the reference's Network got out of the same callables
+            mine = np.asarray(net.nodes[nid].demand, dtype=np.float64)
+            assert mine.shape == arr.shape and np.array_equal(mine, arr), f"demand of node {nid} differs from the reference's"
+        return net
     if g.info.get("randomize_network_seed") is not None:
         # the reference called create_network(name) and then randomize_network(name, seed) on the same generator
         gen = NetworkEnvGenerator(DATA)

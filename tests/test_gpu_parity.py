@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full", "i45_prefix", "delft_prefix",
          "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky", "odd_params", "odd_separators", "star8", "edge_window_gt_T", "edge_empty",
-         "butterfly_scA_full", "butterfly_scB_full", "butterfly_scC_full", "one_intersection_full", "two_coordinators_prefix"]
+         "butterfly_scA_full", "butterfly_scB_full", "butterfly_scC_full", "one_intersection_full", "two_coordinators_prefix", "spike_callable", "melbourne_callable"]
 
 
 def _dev_math(op, a, b=None, seed=0):
@@ -391,12 +391,17 @@ def test_two_stream_plan_gives_identical_histories(name, steps, hist, monkeypatc
         link.back_gate_width = link.back_gate_width       # a setter between the calls (drops the fused fractions)
         net.run(cut, steps)
         first = 0 if hist == "full" else steps - 2       # recent mode: most fields are short rings, compare what they still hold
-        out = {f: e.read_block(LINK_FIELDS[f][0], first, steps) for f in ALL_FIELDS}
+
+        def held(f):     # sending / receiving flow of step t are entries t - 1: in a ring the newest entry is one behind
+            last = steps - 1 if hist == "recent" and f in ("sending_flow", "receiving_flow") else steps
+            return e.read_block(LINK_FIELDS[f][0], min(first, last - 2), last)
+
+        out = {f: held(f) for f in ALL_FIELDS}
         out["tf"] = np.stack([np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 127, 128, 255)])
         out["flags"] = e.error_flags()[1]
         e.reset()
         net.run(1, steps)
-        out2 = {f: e.read_block(LINK_FIELDS[f][0], first, steps) for f in ALL_FIELDS}
+        out2 = {f: held(f) for f in ALL_FIELDS}
         net.close()
         return out, out2
 
@@ -515,6 +520,11 @@ def test_recent_history_mode_gives_the_same_numbers(case):
                 lk.density[stop - 6]
             col = np.asarray(lk.speed)
             assert np.isnan(col[stop - 6]) and col[stop] == g.state("speed")[0, stop]
+            # sending_flow[stop] is written by step stop + 1: its ring slot still holds entry stop - 4, which must not be served
+            with pytest.raises(IndexError):
+                lk.sending_flow[stop]
+            col = np.asarray(lk.sending_flow)
+            assert np.isnan(col[stop]) and col[stop - 1] == g.state("sending_flow")[0, stop - 1]
     assert e.error_flags()[0] == 0
     net.close()
 
