@@ -32,7 +32,7 @@ struct pedn_sim {
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
   int node_waves = 8, node_waves_pr = 6;  // register budget of node_kernel (waves per SIMD) with shared / per-replica link parameters, see pedn_create
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
-  int link_ns = 1;     // segments of 128 replicas per lane of the link update (launch_step); PEDN_LINK_NS=1|2
+  int link_ns = 1;     // segments of 128 replicas per lane of the link update (launch_step); PEDN_LINK_NS=1|2, 0: one replica per lane
   int max_degree = 0;     // largest number of incident corridors of a node
   size_t node_lds = 0;    // dynamic LDS bytes of node_kernel
   hipStream_t stream2 = nullptr;   // second half of the replicas in pedn_run (two_streams)
@@ -656,7 +656,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     s->fuse_tp = 1;
     if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
-    if (const char* f = getenv("PEDN_LINK_NS")) s->link_ns = atoi(f) == 2 ? 2 : 1;
+    if (const char* f = getenv("PEDN_LINK_NS")) s->link_ns = atoi(f) == 2 ? 2 : (atoi(f) == 0 ? 0 : 1);
     for (SlotRec& R : rec) { R.act = -1; R.lp = -1; }
     // two chains of launches (one per half of the replicas) in pedn_run; PEDN_STREAMS=1|2, pedn_set_streams.  Default: models
     // with dynamic turning-fraction rows from 1024 replicas -- their second launch is few long waves at 4 waves per SIMD, and the
@@ -1041,7 +1041,8 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   else hipLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, vn, t);
   // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
   const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0 && !obs_fused) ? 2 : 1;   // (the diagnostic NS = 2 has no OBS instantiation)
-  const unsigned nlb = v.n_pairs_corr > 0 && !s->fuse_link ? (unsigned)(((size_t)v.n_pairs_corr * (v.pr ? v.subRS : v.subRS / (2 * ns)) + 255) / 256) : 0u;
+  const bool one_r = v.pr || (s->link_ns == 0 && !fused && !obs_fused);   // one replica per lane (link_kernel_1r)
+  const unsigned nlb = v.n_pairs_corr > 0 && !s->fuse_link ? (unsigned)(((size_t)v.n_pairs_corr * (one_r ? v.subRS : v.subRS / (2 * ns)) + 255) / 256) : 0u;
   s->second_launch = 1;
   if (fused || obs_fused) {
     const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;
@@ -1065,7 +1066,8 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
 #undef PEDN_LT
     if (fused && half != 0) s->tp_ready = t + 1;   // half 0: the second half of this step still has to see the old value
   } else if (nlb > 0) {
-    if (v.pr) { if (v.hist) launch(link_kernel_pr<true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel_pr<false>, dim3(nlb), dim3(256), 4, v, t); }
+    if (v.pr) { if (v.hist) launch(link_kernel_1r<true, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel_1r<true, false>, dim3(nlb), dim3(256), 4, v, t); }
+    else if (one_r) { if (v.hist) launch(link_kernel_1r<false, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel_1r<false, false>, dim3(nlb), dim3(256), 4, v, t); }
     else if (ns == 2) { if (v.hist) launch(link_kernel<2, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel<2, false>, dim3(nlb), dim3(256), 4, v, t); }
     else { if (v.hist) launch(link_kernel<1, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel<1, false>, dim3(nlb), dim3(256), 4, v, t); }
   }

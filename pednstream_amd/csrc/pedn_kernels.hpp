@@ -1008,8 +1008,9 @@ __device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& P
   if (gb != Pb.width || v.hist) v.f64[F_GATE][at(R64(F_GATE, t), b, L, RS, r)] = gb;
 }
 
-// Same update with per-replica link parameters: one replica per lane (the parameters live in vector registers).
-template <bool HIST>
+// Same update with ONE replica per lane: with per-replica link parameters (PR: they live in vector registers), or with the shared
+// record (PEDN_LINK_NS=0, a diagnostic: twice the waves of link_body<1> at ~45 instead of 69 vector registers, 8-byte accesses).
+template <bool PR, bool HIST>
 __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid) {
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)v.subRS));
@@ -1017,7 +1018,7 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
   if (p >= v.n_pairs_corr) return;
   const CorrRec& C = v.corr_rec[p];
   const int a = C.a, b = C.b;
-  const LinkP Pa = lane_params<true>(v, C.Pa, a, r), Pb = lane_params<true>(v, C.Pb, b, r);
+  const LinkP Pa = lane_params<PR>(v, C.Pa, a, r), Pb = lane_params<PR>(v, C.Pb, b, r);
   const double da = v.f64[F_IN][at(R64(F_IN, t), a, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), a, Lall, RS, r)];
   const double db = v.f64[F_IN][at(R64(F_IN, t), b, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), b, Lall, RS, r)];
   link_update_one<HIST>(v, Pa, Pb, a, b, t, r, da, db, v.f32[G_N][at(R32(G_N, t - 1), a, L, RS, r)], v.f32[G_N][at(R32(G_N, t - 1), b, L, RS, r)]);
@@ -1025,8 +1026,8 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
 
 template <int NS, bool HIST>
 __global__ __launch_bounds__(256) void link_kernel(DevView v, int t) { link_body<NS, HIST>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
-template <bool HIST>
-__global__ __launch_bounds__(256) void link_kernel_pr(DevView v, int t) { link_pr_body<HIST>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
+template <bool PR, bool HIST>
+__global__ __launch_bounds__(256) void link_kernel_1r(DevView v, int t) { link_pr_body<PR, HIST>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
 
 // ---- batched RL glue (rl/builders.py, rl/pz_pednet_env.py:548-581) --------------------------------------------------
 struct RlView {
@@ -1213,7 +1214,7 @@ __global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, uns
     turn_frac_body<PR, true, HIST>(v, t + 1, b < n_tp_heavy ? b : b - n_link_blocks, lds);
   } else if (b < n_tp_heavy + n_link_blocks) {
     const size_t gid = (size_t)(b - n_tp_heavy) * blockDim.x + threadIdx.x;
-    if (PR) link_pr_body<HIST>(v, t, gid);
+    if (PR) link_pr_body<true, HIST>(v, t, gid);
     else link_body<NS, HIST>(v, t, gid);
   } else if (OBS) {
     rl_observe_body<true, HIST>(v, q, t, accumulate, b - n_link_blocks - n_tp_blocks, reinterpret_cast<float*>(lds));

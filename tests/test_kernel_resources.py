@@ -60,7 +60,7 @@ BUDGETS = {
     r"link_turn_kernel<(true|false), (true|false), 1, (true|false)>": (128, 40960, True),
     r"turn_frac_kernel<(true|false), (true|false)>": (128, 40960, True),
     r"link_kernel<1, (true|false)>": (72, None, True),          # 7 waves per SIMD
-    r"link_kernel_pr<(true|false)>": (64, None, False),
+    r"link_kernel_1r<(true|false), (true|false)>": (64, None, False),    # one replica per lane: per-replica parameters, or PEDN_LINK_NS=0
     r"rl_observe_kernel<(true|false)>": (64, 8192, False),
     r"rl_apply_kernel": (64, None, False),
 }

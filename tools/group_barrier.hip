@@ -60,11 +60,11 @@ __global__ __launch_bounds__(256) void rounds_kernel(double* data, int* counters
     if (MODE == FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(&counters[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&counters[g * 64], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one 256-byte line per group
       const int want = B * k;
       int polls = 0;
-      while (__hip_atomic_load(&counters[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&counters[g * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(8);    // ~0.2 us between polls: the pollers must not saturate the path the arrivals take
         if (++polls > (1 << 22)) { atomicExch(error, 1); break; }
       }
     }
@@ -84,7 +84,7 @@ static double run(double* data, int* counters, int* error, int G, int B, int K, 
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemset(data, 0, data_bytes));
-    CK(hipMemset(counters, 0, sizeof(int) * (size_t)G));
+    CK(hipMemset(counters, 0, sizeof(int) * (size_t)G * 64));
     CK(hipMemset(error, 0, sizeof(int)));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
@@ -123,7 +123,7 @@ int main(int argc, char** argv) {
     double* data;
     int *counters, *error;
     CK(hipMalloc(&data, data_bytes));
-    CK(hipMalloc(&counters, sizeof(int) * (size_t)G));
+    CK(hipMalloc(&counters, sizeof(int) * (size_t)G * 64));
     CK(hipMalloc(&error, sizeof(int)));
     for (int xcd = 1; xcd >= 0; --xcd) {
       struct { const char* name; double us; int err; } r[3] = {{"fence", 0, 0}, {"sc1", 0, 0}, {"nosync", 0, 0}};
