@@ -32,7 +32,11 @@ struct pedn_sim {
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
   int node_waves = 8, node_waves_pr = 6;  // register budget of node_kernel (waves per SIMD) with shared / per-replica link parameters, see pedn_create
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
-  int link_ns = 1;     // segments of 128 replicas per lane of the link update (launch_step); PEDN_LINK_NS=1|2, 0: one replica per lane
+  // The link update as a launch of its own runs one replica per lane (link_kernel_1r: 42-47 VGPRs, 8 waves per SIMD; melbourne x 1024
+  // 12.3-12.6 against 12.7-13.1 us with two replicas per lane, profiles/r03_link_kernel_variants.txt); inside link_turn_kernel, whose
+  // budget is set by the turning fractions, it keeps two replicas per lane (half the workgroups).  PEDN_LINK_NS=1|2 forces two replicas
+  // per lane in 1 | 2 segments of 128 replicas everywhere.
+  int link_ns = 0;
   int max_degree = 0;     // largest number of incident corridors of a node
   size_t node_lds = 0;    // dynamic LDS bytes of node_kernel
   hipStream_t stream2 = nullptr;   // second half of the replicas in pedn_run (two_streams)
@@ -656,7 +660,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     s->fuse_tp = 1;
     if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
-    if (const char* f = getenv("PEDN_LINK_NS")) s->link_ns = atoi(f) == 2 ? 2 : (atoi(f) == 0 ? 0 : 1);
+    if (const char* f = getenv("PEDN_LINK_NS")) s->link_ns = atoi(f) == 2 ? 2 : (atoi(f) == 1 ? 1 : 0);
     for (SlotRec& R : rec) { R.act = -1; R.lp = -1; }
     // two chains of launches (one per half of the replicas) in pedn_run; PEDN_STREAMS=1|2, pedn_set_streams.  Default: models
     // with dynamic turning-fraction rows from 1024 replicas -- their second launch is few long waves at 4 waves per SIMD, and the

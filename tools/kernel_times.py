@@ -14,7 +14,7 @@ from bench import replica_demand  # noqa: E402
 from pednstream_amd import NetworkEnvGenerator  # noqa: E402
 
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
-tag = " ".join(f"{k}={os.environ[k]}" for k in ("PEDN_FUSE_LINK", "PEDN_FUSE_TP", "PEDN_NODE_WAVES", "PEDN_LINK_NS", "PEDN_NODE_MD") if k in os.environ)
+tag = " ".join(f"{k}={os.environ[k]}" for k in ("PEDN_FUSE_LINK", "PEDN_FUSE_TP", "PEDN_NODE_WAVES", "PEDN_LINK_NS", "PEDN_NODE_MD", "PEDN_STREAMS") if k in os.environ)
 lib = os.path.basename(os.environ.get("PEDN_HIP_LIB", "libpedn_hip.so"))
 for network in sys.argv[1:]:
     R = 1024
