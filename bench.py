@@ -175,7 +175,7 @@ def live_traffic(workloads, history):
             f, w = counters("FETCH_SIZE", f"pf_{network}_{replicas}", cmd), counters("WRITE_SIZE", f"pw_{network}_{replicas}", cmd)
             out = {"fetch_factor": fetch_factor, "write_factor": write_factor}
             for k in f:
-                if k in ("node_kernel", "link_kernel", "link_turn_kernel") and k in w:
+                if k in ("node_kernel", "link_kernel", "link_kernel_1r", "link_turn_kernel") and k in w:
                     skip = len(f[k]) // 4          # the warm-up launches (and the first, cold ones)
                     out[k] = statistics.mean(f[k][skip:]) * 1024 * fetch_factor + statistics.mean(w[k][skip:]) * 1024 * write_factor
             LIVE_TRAFFIC[(network, replicas)] = out
@@ -411,7 +411,7 @@ def measure(args, network, dist, rank, local_rank, world):
     live = traffic is not None and traffic_src.startswith("live")
     # the second launch's memory-side bytes, for the working set of a step
     traffic2 = None
-    for k2 in ("link_turn_kernel", "link_kernel"):
+    for k2 in ("link_turn_kernel", "link_kernel_1r", "link_kernel"):
         t2, _ = measured_traffic(k2, network, R)
         if t2 is not None:
             traffic2 = t2

@@ -24,6 +24,18 @@ __global__ __launch_bounds__(256) void triad(const double2* a, const double2* b,
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n2) { double2 x = a[i], y = b[i]; out[i] = make_double2(x.x + y.x, x.y + y.y); }
 }
+// 8-byte accesses per lane (the shape of node_kernel's f64 rows): contiguous, and in 512-byte segments (one wave instruction) visited
+// in a scrambled order (n a power of two)
+__global__ __launch_bounds__(256) void triad8(const double* a, const double* b, double* out, size_t n, int scramble) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (scramble) {
+    const size_t nch = n >> 6, c = i >> 6;
+    const size_t pc = (c * 2654435761ull + 12345ull) & (nch - 1);   // odd multiplier: a permutation of the segments
+    i = (pc << 6) | (i & 63);
+  }
+  out[i] = a[i] + b[i];
+}
 __global__ __launch_bounds__(256) void copy(const double2* a, double2* out, size_t n2) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n2) out[i] = a[i];
@@ -72,7 +84,22 @@ int main() {
       std::sort(ms.begin(), ms.end());
       res[mix] = mb[mix] * 1e6 / (ms[ms.size() / 2] * 1e-3) / 1e12;
     }
-    printf("%12zu | %20.0f %7.2f %20.0f %7.2f %14.0f %7.2f %14.0f %7.2f\n", n, mb[0], res[0], mb[1], res[1], mb[2], res[2], mb[3], res[3]);
+    // the 2R:1W mix once more with 8-byte lanes: contiguous, and as scattered 512-byte segments
+    double r8[2];
+    for (int sc = 0; sc < 2; ++sc) {
+      std::vector<float> ms;
+      for (int rep = 0; rep < 12; ++rep) {
+        hipExtLaunchKernelGGL(triad8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, e0, e1, 0, (const double*)a, (const double*)b, o, n, sc);
+        CK(hipEventSynchronize(e1));
+        float t;
+        CK(hipEventElapsedTime(&t, e0, e1));
+        if (rep >= 4) ms.push_back(t);
+      }
+      std::sort(ms.begin(), ms.end());
+      r8[sc] = mb[0] * 1e6 / (ms[ms.size() / 2] * 1e-3) / 1e12;
+    }
+    printf("%12zu | %20.0f %7.2f %20.0f %7.2f %14.0f %7.2f %14.0f %7.2f | 2R:1W 8-byte lanes %5.2f, in scattered 512 B segments %5.2f\n", n, mb[0], res[0], mb[1],
+           res[1], mb[2], res[2], mb[3], res[3], r8[0], r8[1]);
   }
   printf("(durations are the dispatches' own start / stop timestamps)\n");
   return 0;

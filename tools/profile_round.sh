@@ -59,6 +59,7 @@ if [ "$PART" = all ] || [ "$PART" = bench ]; then
   python3 bench.py --network delft > $P/${TAG}_delft_bench_n1.json 2>> $O/bench.err
   python3 bench.py --rl --network 45_intersections --replicas 2048 > $P/${TAG}_bench_rl_config5.json 2>> $O/bench.err
   python3 bench.py --rl --network 45_intersections --replicas 2048 --history recent >> $P/${TAG}_bench_rl_config5.json 2>> $O/bench.err
+  python3 bench.py --rl --randomize --network 45_intersections --replicas 2048 >> $P/${TAG}_bench_rl_config5.json 2>> $O/bench.err
   for r in 2048 3072 4096; do python3 bench.py --replicas $r --no-cpu-baseline --no-extra --steps 200 --warmup 50; done > $P/${TAG}_replica_scaling.jsonl 2>> $O/bench.err
   { python3 bench.py --network nine_intersections --replicas 256 --no-cpu-baseline --no-extra; python3 bench.py --network 45_intersections --replicas 2048 --no-cpu-baseline --no-extra; } > $P/${TAG}_small_configs.jsonl 2>> $O/bench.err
 fi
@@ -69,6 +70,10 @@ if [ "$PART" = all ] || [ "$PART" = extras ]; then
   python3 tools/dropin_time.py > $P/${TAG}_dropin_time.txt 2>> $O/bench.err
   /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/xstream tools/xstream_bench.hip 2> /dev/null && timeout -k 5 60 /tmp/xstream > $P/${TAG}_cross_stream_dependency.txt 2>&1 || true
   /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/valu_rates tools/valu_rates.hip 2> /dev/null && timeout -k 5 60 /tmp/valu_rates > $P/${TAG}_valu_rates.txt 2>&1 || true
+  # stream ceilings by footprint / mix / access width, the per-group barrier, the workgroup timeline of link_turn_kernel
+  /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/mall_stream tools/mall_stream.hip 2> /dev/null && timeout -k 5 200 /tmp/mall_stream > $P/${TAG}_mall_stream_raw.txt 2>&1 || true
+  /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/group_barrier tools/group_barrier.hip 2> /dev/null && timeout -k 5 120 /tmp/group_barrier > $P/${TAG}_group_barrier_raw.txt 2>&1 || true
+  timeout -k 5 200 python3 tools/lt_timeline.py delft 1024 > $P/${TAG}_lt_timeline_raw.txt 2>> $O/bench.err || true
   # the link update inside node_kernel ("last arriver") against the two-launch plan, alternately on this box
   { for i in 1 2; do for f in 0 1; do PEDN_FUSE_LINK=$f python3 tools/kernel_times.py melbourne delft; done; done; } > $P/${TAG}_last_arriver.txt 2>> $O/bench.err
   python3 -m pytest tests -q -m gpu > $P/${TAG}_pytest_gpu.log 2>&1

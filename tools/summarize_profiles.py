@@ -47,7 +47,7 @@ f, w = counters(pf), counters(pw)
 summary = {"calibration": {"known_read_bytes": cal_read_bytes, "FETCH_SIZE_bytes": cal_f, "fetch_factor": fetch_factor,
                            "known_write_bytes": cal_write_bytes, "WRITE_SIZE_bytes": cal_w, "write_factor": write_factor},
            "kernels": {}}
-for k in ("node_kernel", "link_kernel", "link_turn_kernel", "turn_frac_kernel"):
+for k in ("node_kernel", "link_kernel", "link_kernel_1r", "link_turn_kernel", "turn_frac_kernel"):
     if k not in f:
         continue
     fr, wr = f[k][warmup:], w[k][warmup:]
