@@ -996,7 +996,9 @@ __device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& P
   const float oa = win ? v.f32[G_TT][at(R32(G_TT, t - v.W), a, L, RS, r)] : 0.0f, ob = win ? v.f32[G_TT][at(R32(G_TT, t - v.W), b, L, RS, r)] : 0.0f;
   const SpeedOut sa = speed_calc(v, Pa, a, t, r, ka, kb, v.rsum[(size_t)a * RS + r], oa);
   const SpeedOut sb = speed_calc(v, Pb, b, t, r, kb, ka, v.rsum[(size_t)b * RS + r], ob);
-  const double ga = Pa.sep ? wa : v.back[(size_t)a * RS + r], gb = Pb.sep ? wb : v.back[(size_t)b * RS + r];
+  // recorded width (link.py:188 / :451-452): the separator width, or the back gate -- one scalar load when every replica shares it
+  const double bua = v.back_u[a], bub = v.back_u[b];
+  const double ga = Pa.sep ? wa : (bua == bua ? bua : v.back[(size_t)a * RS + r]), gb = Pb.sep ? wb : (bub == bub ? bub : v.back[(size_t)b * RS + r]);
   v.f32[G_N][at(R32(G_N, t), a, L, RS, r)] = na; v.f32[G_N][at(R32(G_N, t), b, L, RS, r)] = nb;
   v.f32[G_K][at(R32(G_K, t), a, L, RS, r)] = ka; v.f32[G_K][at(R32(G_K, t), b, L, RS, r)] = kb;
   v.f32[G_V][at(R32(G_V, t), a, L, RS, r)] = sa.spd; v.f32[G_V][at(R32(G_V, t), b, L, RS, r)] = sb.spd;

@@ -206,7 +206,11 @@ class ScenarioBatch:
             self.demand = {key: v for key, v in self.demand.items() if key[0] != node.node_id}
 
     def commit(self, reset=True):
-        """Upload everything that changed and (by default) reset the state: travel_time[0] depends on the parameters."""
+        """Upload everything that changed and (by default) reset the state: travel_time[0] depends on the parameters.
+
+        A demand array REPLACES the replica's whole row: one shorter than T + 1 is followed by zeros (like ``pedn_set_demand``
+        and like the reference, where ``node.demand`` is the array the generator returned and nothing else), whether the batch
+        covers every replica (one matrix upload) or a subset (``pedn_set_demand_rows``); replicas without an entry keep theirs."""
         net = self.net
         eng = net._flush()
         if self.link_params_dirty:

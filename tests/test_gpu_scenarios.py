@@ -255,3 +255,35 @@ def test_multi_scenario_env_groups_have_their_own_topology():
     problems = compare_fields(lambda nm: e.read_block(LINK_FIELDS[nm][0], 0, steps, rep0=0, rep1=1)[:, :, 0].T, g, e.n_links, steps)
     assert not problems, "\n".join(problems)
     env.close()
+
+
+def test_short_demand_rows_of_a_subset_replace_the_whole_row():
+    """ScenarioBatch.commit with demand arrays shorter than T + 1 for SOME replicas: those rows are the array followed by zeros,
+    the other replicas keep their demand (one pedn_set_demand_rows upload)."""
+    np.random.seed(5)
+    net = NetworkEnvGenerator(DATA).create_network("nine_intersections", verbose=False, n_replicas=6, rng_seed=0)
+    e = net.engine()
+    T = net.simulation_steps
+    origin = next(n for n in net.nodes.values() if n.virtual_incoming_link is not None and n.node_id in net.origin_nodes)
+    before = e.get_demand(origin.index, 1)
+    assert before[200:].sum() > 0
+    batch = ScenarioBatch(net)
+    short = {0: np.arange(1.0, 31.0), 4: np.full(120, 7.0)}
+    for r, arr in short.items():
+        batch.set_replica(r, demand={origin.node_id: arr})
+    batch.commit()
+    for r, arr in short.items():
+        got = e.get_demand(origin.index, r)
+        assert np.array_equal(got[:len(arr)], arr) and not got[len(arr):].any(), r
+    for r in (1, 2, 3, 5):
+        assert np.array_equal(e.get_demand(origin.index, r), before), r
+    net.run(1, 150)
+    model = flatten_network(net)
+    for r in (0, 4, 5):              # and the runs follow those rows
+        o = od.Oracle(model, seed=0, replica=r)
+        o.set_demand(origin.index, short[r] if r in short else before)
+        o.run(1, 150)
+        for nm in ("cumulative_inflow", "density"):
+            mine = e.read_block(LINK_FIELDS[nm][0], 0, 150, rep0=r, rep1=r + 1)[:, :, 0].T
+            assert np.array_equal(mine[:e.n_links], o.field(nm)[:e.n_links, :150]), (r, nm)
+    net.close()
