@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("delft_exp.py", ["4"], "busiest link"),
     ("vec_env_rollout.py", ["64", "40"], "agents"),
     ("ensemble_delft.py", ["256"], "densest link at the end"),
+    ("spike.py", ["8"], "surge demand offered at node 4"),
 ])
 def test_example_runs(script, args, expect, tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)
