@@ -152,7 +152,7 @@ def live_traffic(workloads, history):
         proc = subprocess.Popen([roc, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env,
                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
         try:
-            rc = proc.wait(timeout=90)
+            rc = proc.wait(timeout=150)
         except subprocess.TimeoutExpired:
             os.killpg(proc.pid, signal.SIGKILL)
             proc.wait()

@@ -2,7 +2,7 @@
 
 Needs the profiling build of the engine (`make -C pednstream_amd/csrc phase-profile`, adds ~10 % to the kernel) and a GPU:
 
-    python tools/phase_profile.py melbourne delft
+    python tools/phase_profile.py melbourne delft 45_intersections:2048 nine_intersections:256      # network[:replicas], default 1024
 """
 import ctypes
 import os
@@ -26,9 +26,10 @@ PHASES = ["kernel entry -> slot record", "slot record -> batch of history loads"
 
 def main():
     lib = ctypes.CDLL(LIB)
-    for network in sys.argv[1:] or ["melbourne"]:
+    for spec in sys.argv[1:] or ["melbourne"]:
+        network, _, reps = spec.partition(":")
         gen = NetworkEnvGenerator(os.path.join(ROOT, "data"))
-        R = 1024
+        R = int(reps) if reps else 1024
         net = gen.create_network(network, verbose=False, n_replicas=R, rng_seed=0)
         e = net.engine()
         for nid in net.origin_nodes:
