@@ -43,7 +43,6 @@ struct pedn_sim {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int two_streams = 0;    // pedn_run launches the two halves of the batch on two streams (replicas are independent)
   int second_launch = 0;  // launch_step: a launch followed node_kernel
-  int fuse_link = 0;   // node_kernel<FUSE> also does the link update (the later of a corridor's two end waves): no link launch
   int fuse_tp = 0;     // the link update and the next step's turn probabilities share one launch (launch_step)
   int tp_ran = 0;      // launch_step launched the stand-alone turn_frac_kernel (pedn_profile_step)
   int tp_ready = -1;   // step whose turning fractions are in tfd[step & 1] (written by link_turn_kernel of the step before), -1: none
@@ -166,7 +165,6 @@ static int reset_state(pedn_sim* s) {
   DevView& v = s->v;
   for (int f = 0; f < 4; ++f) HIP_TRY(s, hipMemsetAsync(v.f64[f], 0, (size_t)s->rows64[f] * v.Lall * v.RS * sizeof(double), s->stream));
   HIP_TRY(s, hipMemsetAsync(v.flags, 0, (size_t)v.RS * sizeof(uint32_t), s->stream));
-  HIP_TRY(s, hipMemsetAsync(v.arrive, 0, (size_t)std::max(v.n_pairs_corr, 1) * (v.RS / 64) * sizeof(int32_t), s->stream));
   if (v.L > 0) {
     int max_rows = 0;  // over the fields init_state_kernel fills (all of them have L columns)
     for (int f = 4; f < 7; ++f) max_rows = std::max(max_rows, s->rows64[f]);
@@ -463,20 +461,22 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.cost > b.cost; });
     std::vector<Row> packed;
     std::vector<int> lds_base;
+    int coop_groups = PEDN_TF_COOP_GROUPS;  // rows with more multi-entry groups get a workgroup of their own; PEDN_TF_COOP=n overrides
+    if (const char* d = getenv("PEDN_TF_COOP")) coop_groups = std::max(1, atoi(d));
     int lds_limit = PEDN_TF_LDS_ROWS;  // diagnostics: PEDN_TF_LDS_LIMIT=n gives a row at most n LDS rows (the rest goes to ent_p)
     if (const char* d = getenv("PEDN_TF_LDS_LIMIT")) lds_limit = std::max(0, std::min(atoi(d), PEDN_TF_LDS_ROWS));
     {
       std::vector<char> taken(rows.size(), 0);
       for (size_t a0 = 0; a0 < rows.size(); ++a0) {
         if (taken[a0]) continue;
-        if (rows[a0].groups > PEDN_TF_COOP_GROUPS) {  // a workgroup of its own: four records of the same row (coop)
+        if (rows[a0].groups > coop_groups) {  // a workgroup of its own: four records of the same row (coop)
           taken[a0] = 1;
           for (int k = 0; k < 4; ++k) { packed.push_back(rows[a0]); lds_base.push_back(0); }
           continue;
         }
         int fill = 0, cnt = 0;
         for (size_t k = a0; k < rows.size() && cnt < 4; ++k) {
-          if (taken[k] || rows[k].groups > PEDN_TF_COOP_GROUPS) continue;
+          if (taken[k] || rows[k].groups > coop_groups) continue;
           const int need = std::min(rows[k].need, lds_limit);
           if (k != a0 && fill + need > PEDN_TF_LDS_ROWS) continue;
           taken[k] = 1;
@@ -550,7 +550,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         put_d(&E[4], m->link_vf[l]); put_d(&E[6], m->link_kc[l]); put_d(&E[8], m->link_length[l]);
         if (slot >= 0 && E[2]) any_sep = 1;
       }
-      w[3] = n_g; w[6] = (int)used.size(); w[7] = any_sep; w[107] = over; w[108] = packed[ri].groups > PEDN_TF_COOP_GROUPS;
+      w[3] = n_g; w[6] = (int)used.size(); w[7] = any_sep; w[107] = over; w[108] = packed[ri].groups > coop_groups;
     }
     gwords.resize(gwords.size() + 8 * 32, 0);  // turn_frac_body reads a chunk of four records ahead; padding has n = 0
     rows = packed;
@@ -573,7 +573,6 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     v.n_turns = m->n_turns;
   }
   TRY(upload(s, m->od_w, (size_t)m->n_od * v.T1, &v.od_w));
-  std::vector<int> corr_of;  // link -> corridor
   {  // corridors: one lane of link_kernel updates both directions
     std::vector<CorrRec> cr;
     for (int l = 0; l < L; ++l)
@@ -584,10 +583,6 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       }
     v.n_pairs_corr = (int)cr.size();
     TRY(upload(s, cr.data(), cr.size(), &v.corr_rec));
-    corr_of.assign((size_t)std::max(L, 1), -1);
-    for (size_t p = 0; p < cr.size(); ++p) corr_of[cr[p].a] = corr_of[cr[p].b] = (int)p;
-    TRY(dalloc(s, std::max<size_t>(cr.size(), 1) * (size_t)(v.RS / 64), &v.arrive));
-    HIP_TRY(s, hipMemset(v.arrive, 0, std::max<size_t>(cr.size(), 1) * (size_t)(v.RS / 64) * sizeof(int32_t)));
   }
   {  // bin nodes into blocks of 8 waves: first-fit over the nodes ordered by (expected load, slot count) decreasing, so that
     // every block is full regardless of node degree.  The 8 waves of a block meet at two barriers, so a block lasts as long
@@ -629,8 +624,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
           R.lout = m->slot_out_link[m->node_slot_ptr[n] + k];
           R.turn0 = m->node_turn_ptr[n];
           R.demand_row = m->node_demand_row[n];
-          R.corr = -1;
-          if (R.lin < L) { R.Pin = lp[R.lin]; R.Pout = lp[R.lout]; R.corr = corr_of[R.lout]; }
+          if (R.lin < L) { R.Pin = lp[R.lin]; R.Pout = lp[R.lout]; }
         }
         base += d * d;  // <= 64 tiles because sum(d) <= 8
       }
@@ -668,11 +662,6 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // is smaller (melbourne 38.8 -> 37.3) and the plan stays one chain, whose launches are the ones the roofline figures describe.
     s->two_streams = v.RS >= 1024 && v.n_trow > 0;
     if (const char* f = getenv("PEDN_STREAMS")) s->two_streams = atoi(f) == 2;
-    // PEDN_FUSE_LINK=1: node_kernel<FUSE> does the link update too (the later of a corridor's two end waves) and the link launch
-    // goes away.  Parity-green, but not faster (the update's arithmetic and its extra memory round trip land
-    // on waves that hold a full CU's wave slots), so it is off unless asked for.
-    s->fuse_link = 0;
-    if (const char* f = getenv("PEDN_FUSE_LINK")) s->fuse_link = atoi(f) != 0 && m->node_model != PEDN_NODE_OPTIMAL && s->node_waves == 8;
     s->node_lp = m->node_model == PEDN_NODE_OPTIMAL;
     if (s->node_lp) {  // tableau workspace: one per (regular node, replica group), sized for the largest such node
       int n_lp = 0, max_m = 0;
@@ -1000,12 +989,11 @@ typedef void (*node_kernel_fn)(DevView, int);
 static node_kernel_fn node_kernel_for(const pedn_sim* s) {
   const bool h = s->v.hist != 0;  // recent-history mode: the instantiations that mask the history rows
   const bool d6 = s->max_degree <= 6;  // loops and the row of turning fractions unrolled for 6 instead of 8 corridors per node
-#define PEDN_NK(PR_, W_, LP_, F_) (h ? (d6 ? node_kernel<PR_, W_, LP_, true, F_, 6> : node_kernel<PR_, W_, LP_, true, F_, 8>) \
-                                     : (d6 ? node_kernel<PR_, W_, LP_, false, F_, 6> : node_kernel<PR_, W_, LP_, false, F_, 8>))
-  if (s->node_lp) return s->v.pr ? PEDN_NK(true, 8, true, false) : PEDN_NK(false, 8, true, false);
-  if (s->fuse_link) return s->v.pr ? PEDN_NK(true, 8, false, true) : PEDN_NK(false, 8, false, true);
-  if (s->v.pr) return s->node_waves_pr == 8 ? PEDN_NK(true, 8, false, false) : PEDN_NK(true, 6, false, false);
-  return s->node_waves == 8 ? PEDN_NK(false, 8, false, false) : PEDN_NK(false, 6, false, false);
+#define PEDN_NK(PR_, W_, LP_) (h ? (d6 ? node_kernel<PR_, W_, LP_, true, 6> : node_kernel<PR_, W_, LP_, true, 8>) \
+                                 : (d6 ? node_kernel<PR_, W_, LP_, false, 6> : node_kernel<PR_, W_, LP_, false, 8>))
+  if (s->node_lp) return s->v.pr ? PEDN_NK(true, 6, true) : PEDN_NK(false, 6, true);   // at 8 waves the LP instantiations spill 4..14 vector registers
+  if (s->v.pr) return s->node_waves_pr == 8 ? PEDN_NK(true, 8, false) : PEDN_NK(true, 6, false);
+  return s->node_waves == 8 ? PEDN_NK(false, 8, false) : PEDN_NK(false, 6, false);
 #undef PEDN_NK
 }
 
@@ -1046,7 +1034,7 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
   const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0 && !obs_fused) ? 2 : 1;   // (the diagnostic NS = 2 has no OBS instantiation)
   const bool one_r = v.pr || (s->link_ns == 0 && !fused && !obs_fused);   // one replica per lane (link_kernel_1r)
-  const unsigned nlb = v.n_pairs_corr > 0 && !s->fuse_link ? (unsigned)(((size_t)v.n_pairs_corr * (one_r ? v.subRS : v.subRS / (2 * ns)) + 255) / 256) : 0u;
+  const unsigned nlb = v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (one_r ? v.subRS : v.subRS / (2 * ns)) + 255) / 256) : 0u;
   s->second_launch = 1;
   if (fused || obs_fused) {
     const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;

@@ -611,20 +611,13 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
 // WAVES = waves per SIMD the register allocation aims at.  8 (the default): 59..63 VGPRs, no vector spill, about 20 scalar
 // registers spilled into VGPR lanes, 4 blocks per CU.  6 (PEDN_NODE_WAVES=6, a diagnostic): no spill of any kind, but 94 scalar
-// registers leave 7 waves per SIMD -- slower on every model measured.  tests/test_kernel_resources.py
+// registers leave 7 waves per SIMD -- slower on every model measured -- except with per-replica link
+// parameters (PR: 28 more live vector registers), where 6 is the default (0 spills instead of 2..8).  tests/test_kernel_resources.py
 // guards the budget: one more live register in the wrong place turns the scalar spills into 16 vector spills (+11 us).
 // LP: the node model is the linear programme of assign_flows_type 'optimal' instead of the classic proportional rule.
-// FUSE: the link update of t happens in this launch too.  A corridor's state needs inflow[t] / outflow[t] of both directions,
-// i.e. the results of the two slot waves at its two ends, which run in different workgroups: each wave stores its two flows,
-// releases them at agent scope, then adds to the corridor's arrival counter; the wave whose add comes second acquires at agent
-// scope, loads the other wave's two flows and updates both directions.  No wave waits for another.  The counters are never reset inside a step: every launch adds exactly two, the parity tells first from second.
-template <bool HIST>
-__device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& Pa, const LinkP& Pb, int a, int b, int t, int r,
-                                                double da, double db, float pa, float pb);
-
 // MD: degree the row / column loops and the row of turning fractions are unrolled for (the host picks 6 when no node of the
 // model has more incident corridors: 4 vector registers less in a kernel that lives on its last one)
-template <bool PR, int WAVES, bool LP, bool HIST, bool FUSE = false, int MD = PEDN_MAX_DEGREE>
+template <bool PR, int WAVES, bool LP, bool HIST, int MD = PEDN_MAX_DEGREE>
 __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   // dynamic LDS, sized by the host for the fullest block (pedn_create: node_lds): a block of nodes of degree 3..4 needs 24 of
   // the 64 tiles a single degree-8 node would
@@ -646,13 +639,11 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
 #endif
   const SlotRec& W = v.slot_rec[(size_t)blockIdx.y * 8 + wave];  // wave-uniform: scalar loads
   const int node = W.node, slot = W.slot, base = W.base, m = W.m;
-  const int corr = FUSE ? W.corr : -1;  // read here: behind the hand-off's memory clobber it would be a vector load in front of the add
   const bool active = node >= 0;
   PH(1, lane + node);
   uint32_t fl = 0;
   double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0, co_prev = 0.0, ci_prev = 0.0;
   int lin = 0, lout = 0, kind = 0;
-  float np_in = 0.0f, np_out = 0.0f;  // FUSE: num_pedestrians[t-1] of the slot's two links, kept for their update
   double tfr[MD - 1];
 
   if (active) {
@@ -722,7 +713,6 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
           if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
       }
       if (!Pin.sep) x.k_in = x.n_in / Pin.area32;
-      if (FUSE) { np_in = x.n_in; np_out = x.n_out; }
       co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
       ci_prev = x.ci_out;  // cumulative_inflow[t-1] of the outgoing link
       PH(2, x.n_in + x.k_in + x.att_in + (float)(x.co_in + x.s_prev + x.co_sw + x.ci_out + x.r_prev + x.front_in + x.back_out));
@@ -815,27 +805,8 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     rowp(v.f64[F_CO], R64(F_CO, t), lin, Lall, RS, r0)[lane] = co_prev + qo;
     rowp(v.f64[F_CI], R64(F_CI, t), lout, Lall, RS, r0)[lane] = ci_prev + qi;
     if (fl) atomicOr(&v.flags[r], fl);
-    if (FUSE && lin < L) {
-      // hand-off by the memory model, not by ISA details: plain stores, a release fence at agent scope by every lane (their stores
-      // are written back from this XCD's L2), the arrival counted with an acq_rel add, and an agent-scope acquire fence in the
-      // wave that finds the other end's flows published (its L1 / L2 lines of them are invalidated before the loads)
-      *p_out = qo;
-      *p_in = qi;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      int arrived = 0;
-      if (lane == 0) arrived = __hip_atomic_fetch_add(&v.arrive[(size_t)corr * (size_t)(RS / 64) + (size_t)(r0 >> 6)], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      arrived = __builtin_amdgcn_readfirstlane(arrived);
-      if (arrived & 1) {  // the other end of the corridor has published: Network.update_link_states for both directions
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const double in_lin = rowp(v.f64[F_IN], R64(F_IN, t), lin, Lall, RS, r0)[lane];
-        const double out_lout = rowp(v.f64[F_OUT], R64(F_OUT, t), lout, Lall, RS, r0)[lane];
-        const LinkP Pa = lane_params<PR>(v, W.Pout, lout, r), Pb = lane_params<PR>(v, W.Pin, lin, r);
-        link_update_one<HIST>(v, Pa, Pb, lout, lin, t, r, qi - out_lout, in_lin - qo, np_out, np_in);
-      }
-    } else {
-      *p_out = qo;
-      *p_in = qi;
-    }
+    *p_out = qo;
+    *p_in = qi;
   }
 #ifdef PEDN_PHASE_PROFILE
   PH(9, qo + qi);
@@ -983,7 +954,10 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
 }
 
 // The link update of both directions of one corridor for ONE replica, given inflow[t] - outflow[t] (da, db) and
-// num_pedestrians[t-1] (pa, pb) of the two directions; everything else it needs it loads itself.
+// num_pedestrians[t-1] (pa, pb) of the two directions; everything else it needs it loads itself.  (Round 2 also called it from
+// inside node_kernel -- the later of a corridor's two end waves updated the corridor, PEDN_FUSE_LINK=1.  Parity-green and never
+// faster with write-through hand-off (profiles/r02_last_arriver.txt); with the hand-off the memory model asks for -- agent-scope
+// release / acquire fences = L2 write-back and invalidate per wave -- 18 x slower (profiles/r03_last_arriver.txt).  Removed.)
 template <bool HIST>
 __device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& Pa, const LinkP& Pb, int a, int b, int t, int r,
                                                 double da, double db, float pa, float pb) {

@@ -29,8 +29,7 @@ struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything sta
   // 2 turn_tab[t] / turn_tab_r (every product constant: replica-independent, tabulated and renormalised on the host)
   // act: action slot of the batched RL step that sets this slot's gate (back gate of lout = front gate of lin), -1 none
   // lp: index of the node among those that solve the node LP (assign_flows_type 'optimal'), on the node's slot 0, else -1
-  // corr: index of the corridor (lin, lout) in corr_rec -- its arrival counter in the fused node + link launch -- or -1
-  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, act, lp, corr, pad;
+  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, act, lp, pad0, pad1;
   LinkP Pin, Pout;  // parameters of the incoming / outgoing link of the slot (unused for a virtual pair)
 };
 
@@ -81,7 +80,6 @@ struct DevView {
   const LinkP* lp;
   const SlotRec* slot_rec;
   const CorrRec* corr_rec;
-  int32_t* arrive;  // [n_pairs_corr][RS / 64] arrivals of a corridor's two end waves (fused node + link launch; two per step)
   const int32_t *node_kind, *node_slot_ptr, *node_turn_ptr, *node_demand_row, *node_dyn, *slot_in, *slot_out;
   const int32_t* pair_row;      // [n_pair] where the product's P(down | up, od) is: -1 the constant 1 (single-entry group), else as word 9 + e of a group record
   const int32_t* trow_words;    // [n_trow][PEDN_TROW_WORDS] rows of dynamic nodes, heaviest first

@@ -176,18 +176,18 @@ def test_engine_equals_oracle_on_large_networks(name, replicas, steps):
 @pytest.mark.parametrize("name,steps", [("nine_intersections", 120), ("delft", 40), ("long_corridor", 150)])
 def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
     """The engine picks its launch plan per model: turn probabilities of step t+1 fused into the link update of step t or
-    launched on their own (PEDN_FUSE_TP), node_kernel built for 6 or 8 waves per SIMD (PEDN_NODE_WAVES).  Every plan,
+    launched on their own (PEDN_FUSE_TP), node_kernel built for 6 or 8 waves per SIMD (PEDN_NODE_WAVES), unrolled for 6 or 8
+    corridors per node, the stand-alone link update with one / two / four replicas per lane, the workgroup order inside link_turn_kernel.  Every plan,
     step-by-step stepping with a setter in between (which drops the fused probabilities) and a reset must give the same
     bits in every field; the stand-alone launch is the one the goldens above pin for large models."""
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
 
-    def history(fuse, waves, stepwise, general="0", lds_limit="64", fuse_link="0", md="6", link_ns="0", heavy="2"):
+    def history(fuse, waves, stepwise, general="0", lds_limit="64", md="6", link_ns="0", heavy="2"):
         monkeypatch.setenv("PEDN_TF_HEAVY_GROUPS", heavy)      # which rows of dynamic nodes go in front of the link update inside link_turn_kernel
         monkeypatch.setenv("PEDN_LINK_NS", link_ns)           # stand-alone link update: 0 one replica per lane, 1 | 2 two replicas in 1 | 2 segments
         monkeypatch.setenv("PEDN_FUSE_TP", fuse)
         monkeypatch.setenv("PEDN_NODE_MD", md)                # 8: node_kernel unrolled for 8 corridors per node whatever the model has
-        monkeypatch.setenv("PEDN_FUSE_LINK", fuse_link)       # 1: the link update inside node_kernel (the later of a corridor's two end waves)
         monkeypatch.setenv("PEDN_NODE_WAVES", waves)
         monkeypatch.setenv("PEDN_TF_GENERAL", general)        # 3: softmax groups and row sums through their general (any-size) paths
         monkeypatch.setenv("PEDN_TF_LDS_LIMIT", lds_limit)    # 1: all but one probability of a row overflow from LDS into HBM
@@ -211,9 +211,9 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
 
     ref = history("0", "6", False)
     for variant in (("1", "6", False), ("0", "8", False), ("1", "8", True), ("1", "8", False, "3", "64"), ("0", "8", False, "1", "1"),
-                    ("1", "8", True, "0", "0"), ("1", "8", True, "0", "64", "1"), ("0", "8", False, "0", "64", "1"), ("1", "8", False, "0", "64", "0", "8"), ("1", "6", False, "0", "64", "0", "8"),
-                    ("0", "8", False, "0", "64", "0", "6", "1"), ("0", "8", True, "0", "64", "0", "6", "2"), ("1", "8", False, "0", "64", "0", "6", "2"),
-                    ("1", "8", False, "0", "64", "0", "6", "0", "0"), ("1", "8", True, "0", "64", "0", "6", "0", "100")):
+                    ("1", "8", True, "0", "0"), ("1", "8", False, "0", "64", "8"), ("1", "6", False, "0", "64", "8"),
+                    ("0", "8", False, "0", "64", "6", "1"), ("0", "8", True, "0", "64", "6", "2"), ("1", "8", False, "0", "64", "6", "2"),
+                    ("1", "8", False, "0", "64", "6", "0", "0"), ("1", "8", True, "0", "64", "6", "0", "100")):
         got = history(*variant)
         for f in ALL_FIELDS:
             assert np.array_equal(ref[f], got[f]), (variant, f)
@@ -445,8 +445,8 @@ def test_profile_run_uses_and_reports_the_launch_plan():
     net.close()
 
 
-@pytest.mark.parametrize("fuse_tp,general,lds_limit,fuse_link", [("1", "0", "64", "0"), ("0", "0", "64", "0"), ("1", "3", "1", "0"), ("1", "0", "64", "1")])
-def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, fuse_link, monkeypatch):
+@pytest.mark.parametrize("fuse_tp,general,lds_limit,link_ns", [("1", "0", "64", "0"), ("0", "0", "64", "0"), ("1", "3", "1", "0"), ("1", "0", "64", "1")])
+def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, link_ns, monkeypatch):
     """(with the next step's turn probabilities fused into the link update launch, and launched on their own: nine of the
     networks put separator links into softmax groups, whose density the fused launch re-derives)
     40 random scenarios (random trees + chords, all three fundamental diagrams, separators, controllers, activity,
@@ -460,7 +460,7 @@ def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, 
     monkeypatch.setenv("PEDN_FUSE_TP", fuse_tp)
     monkeypatch.setenv("PEDN_TF_GENERAL", general)
     monkeypatch.setenv("PEDN_TF_LDS_LIMIT", lds_limit)
-    monkeypatch.setenv("PEDN_FUSE_LINK", fuse_link)
+    monkeypatch.setenv("PEDN_LINK_NS", link_ns)          # stand-alone link update: one replica per lane (default) / two
     ran = 0
     for seed in range(3000, 3040):
         adj, params, origins, dests = random_case(seed)

@@ -17,8 +17,7 @@ mkdir -p $O
   PEDN_LINK_NS=1 python3 tools/gpu_fuzz.py $((S+2200)) $((S+2400))
   PEDN_LINK_NS=2 python3 tools/gpu_fuzz.py $((S+2400)) $((S+2500))
   PEDN_TF_HEAVY_GROUPS=0 python3 tools/gpu_fuzz.py $((S+2500)) $((S+2700))
-  echo "# the link update inside node_kernel (PEDN_FUSE_LINK=1, last arriver) and node_kernel unrolled for 8 corridors (PEDN_NODE_MD=8):"
-  PEDN_FUSE_LINK=1 python3 tools/gpu_fuzz.py $((S+1700)) $((S+2000))
+  echo "# node_kernel unrolled for 8 corridors (PEDN_NODE_MD=8):"
   PEDN_NODE_MD=8 python3 tools/gpu_fuzz.py $((S+2000)) $((S+2200))
   echo "# the two halves of the batch as two chains of launches on two streams against one chain (256 replicas per network):"
   python3 tools/gpu_fuzz_chains.py $((S+3000)) $((S+3150))

@@ -74,8 +74,6 @@ if [ "$PART" = all ] || [ "$PART" = extras ]; then
   /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/mall_stream tools/mall_stream.hip 2> /dev/null && timeout -k 5 200 /tmp/mall_stream > $P/${TAG}_mall_stream_raw.txt 2>&1 || true
   /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/group_barrier tools/group_barrier.hip 2> /dev/null && timeout -k 5 120 /tmp/group_barrier > $P/${TAG}_group_barrier_raw.txt 2>&1 || true
   timeout -k 5 200 python3 tools/lt_timeline.py delft 1024 > $P/${TAG}_lt_timeline_raw.txt 2>> $O/bench.err || true
-  # the link update inside node_kernel ("last arriver") against the two-launch plan, alternately on this box
-  { for i in 1 2; do for f in 0 1; do PEDN_FUSE_LINK=$f python3 tools/kernel_times.py melbourne delft; done; done; } > $P/${TAG}_last_arriver.txt 2>> $O/bench.err
   python3 -m pytest tests -q -m gpu > $P/${TAG}_pytest_gpu.log 2>&1
 fi
 ls -la $P
