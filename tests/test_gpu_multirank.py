@@ -126,3 +126,21 @@ def test_bench_under_the_launcher_runs_the_rccl_branch_once():
     strong = line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                    "--master-port", str(_free_port()), bench, "--total-replicas", "512"] + short)
     assert strong["scaling"] == "strong" and strong["config"]["replicas_per_gpu"] == 512 and strong["config"]["replicas_total"] == 512
+
+
+def test_bench_rl_lines_plain_and_randomized():
+    """The config #5 measurement that rides in the driver's bench line (bench.py: measure_rl), at a small size: both variants
+    produce a complete line, the randomised one really ran with per-env scenarios."""
+    import json
+    import subprocess
+
+    pytest.importorskip("torch")
+    bench = os.path.join(ROOT, "bench.py")
+    for extra in ([], ["--randomize"]):
+        out = subprocess.run([sys.executable, bench, "--rl", "--network", "45_intersections", "--replicas", "128", "--steps", "12", "--warmup", "3"] + extra,
+                             capture_output=True, text=True, cwd=ROOT, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["unit"] == "env-steps/s" and d["value"] > 0 and d["steps"] == 12 and d["randomized"] == bool(extra)
+        assert 0 < d["whole_step_frac"] < 1 and d["device_ms_per_step"] > 0
+        assert ("randomized_reset_s" in d) == bool(extra)

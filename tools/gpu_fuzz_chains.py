@@ -47,7 +47,9 @@ for seed in range(lo, hi):
             n = min(int(rng.integers(3, 60)), T - t)
             net.run(t, t + n, check=False)
             t += n
-        fields = {f: e.read_block(LINK_FIELDS[f][0], first, T) for f in ALL_FIELDS}
+        # sending / receiving flow of step t are entries t - 1: in recent-history mode their ring ends one entry earlier
+        last = {f: T - 1 if first and f in ("sending_flow", "receiving_flow") else T for f in ALL_FIELDS}
+        fields = {f: e.read_block(LINK_FIELDS[f][0], min(first, last[f] - 2), last[f]) for f in ALL_FIELDS}
         fields["flags"] = e.error_flags()[1]
         fields["tf"] = np.stack([np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 127, 128, 255)])
         out.append(fields)
