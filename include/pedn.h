@@ -146,7 +146,9 @@ typedef struct pedn_model_desc {
    * PEDN_HIST_RECENT: only what the recurrence itself looks far back into is kept whole -- inflow and cumulative_inflow
    * (link.py:199-214,284-288: data-dependent look-back); cumulative_outflow keeps max(tau_shockwave) + 2 entries, travel_time
    * the moving-average window + 2, everything else the last 4.  Same numbers step for step (the batched RL environment
-   * reads nothing older); pedn_read of an entry that has left its ring fails.  16 B + a few rows instead of 80 B. */
+   * reads nothing older); pedn_read of an entry that has left its ring fails, and so does one of an entry not written yet whose
+   * ring slot still holds an older one (sending_flow / receiving_flow of step t are entries t-1, node.py:206, link.py:367: after
+   * step t their newest entry is t-1).  16 B + a few rows instead of 80 B. */
   int32_t history_mode;
 
   /* PEDN_NODE_CLASSIC: RegularNode.solve('classic') (node.py:272-300).  PEDN_NODE_OPTIMAL: assign_flows_type 'optimal', the
@@ -185,9 +187,11 @@ int pedn_set_widths(pedn_sim* sim, int32_t which, const double* values);
 /* current widths -> values[n_links][n_replicas] (the device may have changed them through pedn_rl_apply_actions) */
 int pedn_get_widths(pedn_sim* sim, int32_t which, double* values);
 
-/* one step t in 1..T-1 for every replica; asynchronous */
+/* one step t in 1..T for every replica; asynchronous.  (The reference's loops run t = 1 .. T-1, network.py:266-287 callers; its
+ * arrays have T+1 entries like these, so t = T is a valid step -- the batched RL env takes it.  Behind step T no turning fractions
+ * of T+1 are prepared: the per-step tables end at T.) */
 int pedn_step(pedn_sim* sim, int32_t t);
-/* steps t0 .. t1-1 enqueued back to back; asynchronous */
+/* steps t0 .. t1-1 enqueued back to back, t1 <= T+1; asynchronous */
 int pedn_run(pedn_sim* sim, int32_t t0, int32_t t1);
 int pedn_synchronize(pedn_sim* sim);
 /* synchronises; flags[n_replicas] may be NULL; returns the OR over replicas (>= 0) or a negative code */
