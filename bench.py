@@ -533,23 +533,40 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.network == "melbourne" and args.replicas == 1024 and not args.total_replicas:
         import copy
         keep = ("value", "unit", "ms_per_step", "device_ms_per_step", "config", "roofline")
-        # BASELINE config #3 (the network BASELINE.json names for the rocprof roofline), same engine, same run
-        ex, net3, origins3 = measure(args, "delft", None, 0, local_rank, 1)
-        if not args.no_cpu_baseline:
-            ex["cpu_baseline"] = cpu_baseline(flatten_network(net3), net3, origins3, "delft", seconds_target=4.0)
-        net3.close()
-        out["extra"] = {"config3_delft_x1024": {k: ex[k] for k in keep + (("cpu_baseline",) if "cpu_baseline" in ex else ())}}
-        # the same headline network with a working set beyond the 256 MB Infinity Cache (4096 replicas: the per-GPU shape of nothing in
-        # BASELINE, but the point where "hbm" means HBM), with its own counter passes
-        a4 = copy.copy(args)
-        a4.replicas, a4.steps, a4.warmup, a4.no_extra = 4096, min(args.steps, 120), min(args.warmup, 30), True
-        ex4, net4, _ = measure(a4, "melbourne", None, 0, local_rank, 1)
-        net4.close()
-        out["extra"]["hbm_proper_melbourne_x4096"] = {k: ex4[k] for k in keep}
+        out["extra"] = {}
+
+        def extra(name, fn):
+            """An extra must never cost the headline line: a failure is reported in its place."""
+            try:
+                out["extra"][name] = fn()
+            except (Exception, SystemExit) as exc:    # noqa: BLE001  (measure() leaves through SystemExit when error flags are set)
+                out["extra"][name] = {"error": f"{type(exc).__name__}: {exc}"}
+
+        def config3():
+            # BASELINE config #3 (the network BASELINE.json names for the rocprof roofline), same engine, same run
+            ex, net3, origins3 = measure(args, "delft", None, 0, local_rank, 1)
+            try:
+                if not args.no_cpu_baseline:
+                    ex["cpu_baseline"] = cpu_baseline(flatten_network(net3), net3, origins3, "delft", seconds_target=4.0)
+            finally:
+                net3.close()
+            return {k: ex[k] for k in keep + (("cpu_baseline",) if "cpu_baseline" in ex else ())}
+
+        def hbm_proper():
+            # the same headline network with a working set beyond the 256 MB Infinity Cache (4096 replicas: the per-GPU shape of nothing
+            # in BASELINE, but the point where "hbm" means HBM), with its own counter passes
+            a4 = copy.copy(args)
+            a4.replicas, a4.steps, a4.warmup, a4.no_extra = 4096, min(args.steps, 120), min(args.warmup, 30), True
+            ex4, net4, _ = measure(a4, "melbourne", None, 0, local_rank, 1)
+            net4.close()
+            return {k: ex4[k] for k in keep}
+
+        extra("config3_delft_x1024", config3)
+        extra("hbm_proper_melbourne_x4096", hbm_proper)
         # BASELINE config #5: the batched RL env step on 45_intersections x 2048 envs, shared scenario and per-env randomised scenarios
-        out["extra"]["config5_rl_45int_x2048"] = {
+        extra("config5_rl_45int_x2048", lambda: {
             "plain": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=False),
-            "randomized": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=True)}
+            "randomized": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=True)})
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
