@@ -641,6 +641,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       }
       s->node_lds = (size_t)((m->node_model == PEDN_NODE_OPTIMAL ? 16 : 8) + tiles) * 64 * sizeof(double);
       if (const char* f = getenv("PEDN_NODE_LDS_FULL")) if (atoi(f)) s->node_lds = (size_t)(16 + 64) * 64 * sizeof(double);
+      // diagnostic: request at least this many bytes, i.e. hold node_kernel to fewer than 4 blocks per CU (wave places left for the
+      // other chain's launches under the two-chain plan)
+      if (const char* f = getenv("PEDN_NODE_LDS_MIN")) s->node_lds = std::max(s->node_lds, (size_t)atoi(f));
     }
     // register budget of node_kernel: compiled for 8 waves per SIMD (64 VGPRs, a few SGPR spills) or for 6 (measured: delft 32.6
     // against 35.0 us, melbourne 25.8 against 27.1); PEDN_NODE_WAVES=6|8 overrides
