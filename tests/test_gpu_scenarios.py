@@ -160,7 +160,7 @@ def test_vectorised_randomisation_draws_the_reference_ranges_for_every_env():
 
 def test_two_chains_of_launches_with_per_replica_scenarios_and_with_the_node_lp(monkeypatch):
     """The two-stream plan of pedn_run (tests/test_gpu_parity.py) through the kernel instantiations it does not reach there:
-    per-replica link parameters / OD weights / demand (node_kernel<PR>, link_kernel_pr, turn_frac_kernel<PR>) and the node LP
+    per-replica link parameters / OD weights / demand (node_kernel<PR>, link_kernel_1r<PR>, turn_frac_kernel<PR>) and the node LP
     (its tableau workspace is indexed by replica group).  Same bits as one chain of launches."""
     from pednstream_amd import NetworkEnvGenerator
     from pednstream_amd.network import LINK_FIELDS
