@@ -225,6 +225,10 @@ int pedn_profile_step(pedn_sim* sim, int32_t t, float ms[3]);
  * side (2: the two halves of the replicas on two streams -- a launch then covers n_replicas / 2 and overlaps the other
  * chain's launches, so per-launch bandwidths of the two chains add up). */
 int pedn_profile_run(pedn_sim* sim, int32_t t0, int32_t t1, float ms[3], int32_t* chains);
+/* The same range, not averaged: out[5 * row + {0..4}] = {step, chain (0 / 1), kind (0 stand-alone turning fractions, 1 node kernel,
+ * 2 the launch behind it), start, end} with start / end in milliseconds after the start of the range's first launch; at most
+ * `capacity` rows (3 per step and chain), *n_rows of them written.  Shows how the launches of the two chains overlap. */
+int pedn_profile_timeline(pedn_sim* sim, int32_t t0, int32_t t1, float* out, int32_t capacity, int32_t* n_rows, int32_t* chains);
 
 /* launch plan of pedn_run for long ranges: 1 = one chain of launches on the engine's stream, 2 = the two halves of the
  * replicas as two chains on two streams (the default from 1024 replicas; replicas are independent, results are the same) */

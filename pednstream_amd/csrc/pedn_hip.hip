@@ -1158,10 +1158,11 @@ int pedn_set_streams(pedn_sim* s, int32_t n) {
   return PEDN_OK;
 }
 
-int pedn_profile_run(pedn_sim* s, int32_t t0, int32_t t1, float ms[3], int32_t* chains) {
-  if (!s || !ms || !chains) return fail(s, PEDN_E_ARG, "null argument");
-  if (t0 < 1 || t1 > s->v.T1 || t0 >= t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
-  HIP_TRY(s, hipSetDevice(s->device));
+// Steps [t0, t1) under pedn_run's plan with every launch bracketed by its dispatch timestamps.  rows: one per launch,
+// {step, chain, kind (0 stand-alone turning fractions, 1 node_kernel, 2 the launch behind it), start, end} in ms after the start of
+// the first launch of the range.
+struct ProfRow { int t, chain, kind; float start, end; };
+static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows, int* chains) {
   const bool two = two_chains(s, t0, t1);
   const int halves = two ? 2 : 1, n = (t1 - t0) * halves;
   struct Events {  // destroyed on every way out of the function
@@ -1189,17 +1190,54 @@ int pedn_profile_run(pedn_sim* s, int32_t t0, int32_t t1, float ms[3], int32_t* 
   }
   HIP_TRY(s, hipGetLastError());
   HIP_TRY(s, hipStreamSynchronize(s->stream));
+  // the first launch of the range (chain 0): its node_kernel, or the stand-alone turning fractions in front of it
+  hipEvent_t origin = tp_ran[0] ? ev[0] : ev[2];
+  rows.clear();
+  for (int k = 0; k < n; ++k) {
+    const int t = t0 + k / halves, chain = k % halves;
+    for (int kind = 0; kind < 3; ++kind) {
+      if ((kind == 0 && !tp_ran[k]) || (kind == 2 && !second[k])) continue;
+      ProfRow r{t, chain, kind, 0.0f, 0.0f};
+      HIP_TRY(s, hipEventElapsedTime(&r.start, origin, ev[(size_t)k * 6 + 2 * kind]));
+      HIP_TRY(s, hipEventElapsedTime(&r.end, origin, ev[(size_t)k * 6 + 2 * kind + 1]));
+      rows.push_back(r);
+    }
+  }
+  *chains = halves;
+  return PEDN_OK;
+}
+
+int pedn_profile_run(pedn_sim* s, int32_t t0, int32_t t1, float ms[3], int32_t* chains) {
+  if (!s || !ms || !chains) return fail(s, PEDN_E_ARG, "null argument");
+  if (t0 < 1 || t1 > s->v.T1 || t0 >= t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
+  HIP_TRY(s, hipSetDevice(s->device));
+  std::vector<ProfRow> rows;
+  int ch = 1;
+  const int rc = profile_range(s, t0, t1, rows, &ch);
+  if (rc != PEDN_OK) return rc;
   double sum[3] = {0, 0, 0};
   int cnt[3] = {0, 0, 0};
-  for (int k = 0; k < n; ++k) {
-    float d = 0.0f;
-    if (tp_ran[k]) { HIP_TRY(s, hipEventElapsedTime(&d, ev[(size_t)k * 6], ev[(size_t)k * 6 + 1])); sum[0] += d; ++cnt[0]; }
-    HIP_TRY(s, hipEventElapsedTime(&d, ev[(size_t)k * 6 + 2], ev[(size_t)k * 6 + 3]));
-    sum[1] += d; ++cnt[1];
-    if (second[k]) { HIP_TRY(s, hipEventElapsedTime(&d, ev[(size_t)k * 6 + 4], ev[(size_t)k * 6 + 5])); sum[2] += d; ++cnt[2]; }
-  }
+  for (const ProfRow& r : rows) { sum[r.kind] += (double)r.end - (double)r.start; ++cnt[r.kind]; }
   for (int i = 0; i < 3; ++i) ms[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : 0.0f;
-  *chains = halves;
+  *chains = ch;
+  return PEDN_OK;
+}
+
+int pedn_profile_timeline(pedn_sim* s, int32_t t0, int32_t t1, float* out, int32_t capacity, int32_t* n_rows, int32_t* chains) {
+  if (!s || !out || !n_rows || !chains) return fail(s, PEDN_E_ARG, "null argument");
+  if (t0 < 1 || t1 > s->v.T1 || t0 >= t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
+  HIP_TRY(s, hipSetDevice(s->device));
+  std::vector<ProfRow> rows;
+  int ch = 1;
+  const int rc = profile_range(s, t0, t1, rows, &ch);
+  if (rc != PEDN_OK) return rc;
+  if ((int)rows.size() > capacity) return fail(s, PEDN_E_ARG, "timeline buffer too small: " + std::to_string(rows.size()) + " rows");
+  for (size_t i = 0; i < rows.size(); ++i) {
+    out[5 * i] = (float)rows[i].t; out[5 * i + 1] = (float)rows[i].chain; out[5 * i + 2] = (float)rows[i].kind;
+    out[5 * i + 3] = rows[i].start; out[5 * i + 4] = rows[i].end;
+  }
+  *n_rows = (int32_t)rows.size();
+  *chains = ch;
   return PEDN_OK;
 }
 

@@ -151,6 +151,7 @@ def _load():
         "pedn_reset": (C.c_int, [P]),
         "pedn_profile_step": (C.c_int, [P, C.c_int32, C.POINTER(C.c_float)]),
         "pedn_profile_run": (C.c_int, [P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+        "pedn_profile_timeline": (C.c_int, [P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "pedn_set_streams": (C.c_int, [P, C.c_int32]),
         "pedn_set_link_params": (C.c_int, [P, _F64P, _F64P, _F64P, _I32P, _I32P, _F32P]),
         "pedn_set_od_weights_per_replica": (C.c_int, [P, _F64P]),
@@ -182,7 +183,7 @@ def lib():
 EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand", "pedn_set_demand_matrix", "pedn_set_demand_rows", "pedn_get_demand", "pedn_draw_demand",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
-           "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_set_streams", "pedn_rl_configure",
+           "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_rl_configure",
            "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
            "pedn_set_od_weights_per_replica"]
 
@@ -376,6 +377,15 @@ class Engine:
         chains = C.c_int32(0)
         self._ck(self._lib.pedn_profile_run(self._h, int(t0), int(t1), ms, C.byref(chains)))
         return tuple(float(x) for x in ms), int(chains.value)
+
+    def profile_timeline(self, t0, t1):
+        """The launches of steps t0 <= t < t1 one by one: (rows [n, 5] = step, chain, kind (0 stand-alone turning fractions, 1 node
+        kernel, 2 the launch behind it), start ms, end ms after the first launch's start; chains)."""
+        cap = 6 * (int(t1) - int(t0))
+        buf = np.zeros(5 * cap, dtype=np.float32)
+        n, chains = C.c_int32(0), C.c_int32(0)
+        self._ck(self._lib.pedn_profile_timeline(self._h, int(t0), int(t1), buf.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n), C.byref(chains)))
+        return buf[:5 * n.value].reshape(-1, 5).astype(np.float64), int(chains.value)
 
     def set_streams(self, n):
         """Launch plan of run() for long ranges: 1 chain of launches, or 2 (the halves of the replica batch on two streams)."""
