@@ -14,6 +14,8 @@
 //   wide        two replicas per lane (16-byte f64 / 8-byte f32 accesses), half the replica groups: 8 x 123 blocks
 //   binfast     grid (bins, replica groups): consecutive workgroups are different bins of one replica group (the real kernel: the
 //               replica group is the fastest index)
+//   pipe2       every block handles TWO bins: the batches of both are issued up front, then the first bin is finished (look-back,
+//               barriers, stores) while the second one's loads are in flight -- half the blocks, one generation of waves
 //   packed      what if everything a wave reads sat next to each other?  its 9 loads come from ONE contiguous 4.6 KB chunk per
 //               (slot, replica group) and its 6 stores go to another: same bytes, same waves, perfect locality
 //
@@ -37,7 +39,7 @@ struct View {
   int cols, RS, rows;
 };
 
-enum { FULL = 0, NODEP, NOBAR, NOREC, LOADS1, WIDE, BINFAST, PACKED };
+enum { FULL = 0, NODEP, NOBAR, NOREC, LOADS1, WIDE, BINFAST, PACKED, PIPE2 };
 
 template <typename T>
 __device__ __forceinline__ T* rowp(T* base, int row, int col, int cols, int RS, int r0) {
@@ -108,6 +110,49 @@ __global__ __launch_bounds__(512, 8) void pattern(View v, int t) {
   rowp(v.IN, t & M, lout, cols, RS, r0)[lane] = qi;
   rowp(v.CO, t & M, lin, cols, RS, r0)[lane] = co_in + qo;
   rowp(v.CI, t & M, lout, cols, RS, r0)[lane] = ci_out + qi;
+}
+
+struct Batch { float n_in, n_out, att; double co_in, s_prev, co_sw, ci_out, r_prev; int lin, lout; double p0; };
+
+__global__ __launch_bounds__(512, 8) void pattern_pipe2(View v, int t, int half_bins) {
+  __shared__ double lds[2 * 8 * 64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+  const int RS = v.RS, cols = v.cols, M = v.rows - 1, r0 = (int)blockIdx.x * 64, tp = t - 1;
+  Batch b[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int slot = ((int)blockIdx.y + k * half_bins) * 8 + wave;
+    const Rec& W = v.rec[slot];
+    const int lin = W.lin, lout = W.lout, tau_sw = W.tau_sw;
+    b[k].lin = lin; b[k].lout = lout; b[k].p0 = W.params[5];
+    b[k].n_in = rowp(v.N, tp & M, lin, cols, RS, r0)[lane]; b[k].n_out = rowp(v.N, tp & M, lout, cols, RS, r0)[lane];
+    b[k].att = rowp(v.ATT, tp & M, lin, cols, RS, r0)[lane];
+    b[k].co_in = rowp(v.CO, tp & M, lin, cols, RS, r0)[lane]; b[k].s_prev = rowp(v.S, (tp - 1) & M, lin, cols, RS, r0)[lane];
+    b[k].co_sw = rowp(v.CO, (tp + 1 - tau_sw) & M, lout, cols, RS, r0)[lane]; b[k].ci_out = rowp(v.CI, tp & M, lout, cols, RS, r0)[lane];
+    b[k].r_prev = rowp(v.R, (tp - 1) & M, lout, cols, RS, r0)[lane];
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int slot = ((int)blockIdx.y + k * half_bins) * 8 + wave, lin = b[k].lin, lout = b[k].lout;
+    const int tau = 2 + slot % 18 + (((int)b[k].att) & 1);
+    const double ci_look = rowp(v.CI, (tp + 1 - tau) & M, lin, cols, RS, r0)[lane];
+    const double s_i = (double)(b[k].n_in + b[k].n_out) + b[k].co_in + b[k].s_prev + ci_look * b[k].p0, r_i = b[k].co_sw + b[k].ci_out + b[k].r_prev;
+    rowp(v.S, tp & M, lin, cols, RS, r0)[lane] = s_i;
+    rowp(v.R, tp & M, lout, cols, RS, r0)[lane] = r_i;
+    lds[wave * 64 + lane] = s_i;
+    lds[(8 + wave) * 64 + lane] = r_i;
+    __syncthreads();
+    const double qo = lds[((wave + 1) & 7) * 64 + lane] + r_i;
+    __syncthreads();
+    lds[wave * 64 + lane] = qo;
+    __syncthreads();
+    const double qi = lds[((wave + 7) & 7) * 64 + lane] + s_i;
+    __syncthreads();
+    rowp(v.OUT, t & M, lin, cols, RS, r0)[lane] = qo;
+    rowp(v.IN, t & M, lout, cols, RS, r0)[lane] = qi;
+    rowp(v.CO, t & M, lin, cols, RS, r0)[lane] = b[k].co_in + qo;
+    rowp(v.CI, t & M, lout, cols, RS, r0)[lane] = b[k].ci_out + qi;
+  }
 }
 
 // two replicas per lane: 16-byte f64 and 8-byte f32 accesses, a wave covers 128 replicas
@@ -200,6 +245,7 @@ int main(int argc, char** argv) {
   RUN(LOADS1, "loads1", 16);
   RUN(PACKED, "packed", 9 * 8 + 6 * 8);
   report("binfast", time_launches([&](int t, hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(pattern<BINFAST>, dim3(bins, RS / 64), block, 0, 0, a, b, 0, v, t); }, 60), 108);
+  report("pipe2", time_launches([&](int t, hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(pattern_pipe2, dim3(RS / 64, (bins + 1) / 2), block, 0, 0, a, b, 0, v, t, bins / 2); }, 60), 108);
   report("wide", time_launches([&](int t, hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(pattern_wide, dim3(RS / 128, bins), block, 0, 0, a, b, 0, v, t); }, 60), 108);
   RUN(FULL, "full", 108);
   return 0;
