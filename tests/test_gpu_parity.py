@@ -432,8 +432,14 @@ def test_profile_run_uses_and_reports_the_launch_plan():
     assert chains == 2 and ms[1] > 0 and ms[2] > 0
     ms, chains = e.profile_run(40, 44)            # too short to pay for the fork and the join
     assert chains == 1
+    rows, chains = e.profile_timeline(44, 56)     # the same, launch by launch: (step, chain, kind, start ms, end ms)
+    assert chains == 2 and rows.shape == (12 * 2 * 2, 5) and set(rows[:, 1]) == {0.0, 1.0} and set(rows[:, 2]) == {1.0, 2.0}
+    assert (rows[:, 4] > rows[:, 3]).all() and rows[0, 3] == 0.0
+    for c in (0, 1):                              # within a chain the launches follow one another
+        mine = rows[rows[:, 1] == c]
+        assert (mine[1:, 3] >= mine[:-1, 4] - 1e-6).all()
     e.set_streams(1)
-    ms, chains = e.profile_run(44, 80)
+    ms, chains = e.profile_run(56, 80)
     assert chains == 1 and ms[1] > 0
     timed = {f: e.read_block(LINK_FIELDS[f][0], 0, 80) for f in ALL_FIELDS}
     e.reset()
