@@ -89,6 +89,8 @@ def direct_case(case, adj, params, origin_nodes, destination_nodes=(), steps=Non
         for (mt, kind, u, v, val) in muts:
             if mt == t and kind == "back_gate_set":
                 n.links[(u, v)].back_gate_width = val
+            elif mt == t and kind == "front_gate_set":
+                n.links[(u, v)].front_gate_width = val
             elif mt == t and kind == "separator_set":
                 n.links[(u, v)].separator_width = val
 
@@ -525,6 +527,11 @@ for _r in range(4):
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import demand_callables as dc  # noqa: E402
 
+CASES.update({   # the calling sequence of examples/forky_queues.py:71-118: a front gate narrowed BEFORE the first step, opened at a later one
+    "forky_front": lambda: direct_case("forky_front", FORKY_ADJ, dict(FORKY_PARAMS, simulation_steps=420), [0, 4], tf_nodes=[1],
+                                       tf_values=[[1, 0, 0.5, 0.5, 0, 1]], seed=8, replica=3,
+                                       mutations=[(0, "front_gate_set", 1, 2, 0.5), (260, "front_gate_set", 1, 2, 3)]),
+})
 CASES.update({   # custom demand callables through the boundary (examples/spike.py:85-121, examples/Melbourne.py:36)
     "spike_callable": lambda: direct_case("spike_callable", dc.SPIKE_ADJ, dc.spike_params(), [4], tf_nodes=[4], tf_values=[[1, 0, 0, 1, 0, 1]],
                                           seed=6, replica=2, demand_pattern=[dc.plateau_pattern]),

@@ -252,6 +252,8 @@ def run_reference(name, steps=None, seed=0, replica=0, mode="philox", mutate=Non
     static = dump_static(network)
     tf_hist = {}
     with InjectedRNG(network, seed=seed, replica=replica, mode=mode) as inj:
+        if mutate is not None:
+            mutate(network, 0)          # changes made before the first step (examples/forky_queues.py:112)
         for t in range(1, last):
             network.network_loading(t)
             if record_tf:

@@ -103,6 +103,8 @@ def apply_mutation(net, mut):
         link.back_gate_width = link.back_gate_width + val
     elif kind == "back_gate_set":
         link.back_gate_width = val
+    elif kind == "front_gate_set":
+        link.front_gate_width = val
     elif kind == "separator_set":
         link.separator_width = val
     else:
@@ -122,10 +124,11 @@ def run_oracle(g: Golden, net=None, steps=None):
             o.set_tf(node.index, tf[:, 0])
     last = g.steps if steps is None else min(steps, g.steps)
     tfh = []
-    for t in range(1, last):
-        o.step(t)
-        tfh.append(o.tf())
-        for mut in g.mutations:
+    for t in range(0, last):
+        if t > 0:
+            o.step(t)
+            tfh.append(o.tf())
+        for mut in g.mutations:          # t = 0: changes made before the first step
             if mut[0] == t:
                 apply_mutation(net, mut)
                 for which, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3)):

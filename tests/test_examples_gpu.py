@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("vec_env_rollout.py", ["64", "40"], "agents"),
     ("ensemble_delft.py", ["256"], "densest link at the end"),
     ("spike.py", ["8"], "surge demand offered at node 4"),
+    ("forky_queues.py", [], "pedestrians on the bottleneck link (1,2)"),
 ])
 def test_example_runs(script, args, expect, tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)

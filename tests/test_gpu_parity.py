@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full", "i45_prefix", "delft_prefix",
          "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky", "odd_params", "odd_separators", "star8", "edge_window_gt_T", "edge_empty",
-         "butterfly_scA_full", "butterfly_scB_full", "butterfly_scC_full", "one_intersection_full", "two_coordinators_prefix", "spike_callable", "melbourne_callable"]
+         "butterfly_scA_full", "butterfly_scB_full", "butterfly_scC_full", "one_intersection_full", "two_coordinators_prefix", "spike_callable", "melbourne_callable", "forky_front"]
 
 
 def _dev_math(op, a, b=None, seed=0):
@@ -61,10 +61,11 @@ def _run_engine_on_golden(g, n_replicas=1):
     net = build_network(g, n_replicas=n_replicas, replica_offset=g.replica, rng_seed=g.seed, rng_mode=g.mode)
     last = g.steps
     tfh = []
-    for t in range(1, last):
-        net.network_loading(t)
-        tfh.append(np.concatenate([net._engine.get_turning_fractions(nd.index, 0) for nd in net.nodes.values()]))
-        for mut in g.mutations:
+    for t in range(0, last):
+        if t > 0:
+            net.network_loading(t)
+            tfh.append(np.concatenate([net._engine.get_turning_fractions(nd.index, 0) for nd in net.nodes.values()]))
+        for mut in g.mutations:          # t = 0: changes made before the first step (examples/forky_queues.py:112)
             if mut[0] == t:
                 apply_mutation(net, mut)
     return net, np.array(tfh)
