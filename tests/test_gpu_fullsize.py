@@ -82,6 +82,38 @@ def test_full_size_batch_under_the_default_plan(name, R, steps):
     net.close()
 
 
+def test_largest_single_gpu_batch_melbourne_4608():
+    """More than BASELINE config #4's whole ensemble on ONE GPU (melbourne x 4608 replicas, 173 GB of histories): the flow and
+    cumulative-count fields hold more than 2^31 ELEMENTS, every field more than 2^32 bytes -- any 32-bit index would show.  First,
+    middle and last replica bit-exact against the oracle, no error flag."""
+    R, steps = 4608, 500                   # element index (t * columns + column) * replicas + replica passes 2^31 at t = 476
+    np.random.seed(7)
+    net = NetworkEnvGenerator(DATA).create_network("melbourne", verbose=False, n_replicas=R, rng_seed=5)
+    e = net.engine()
+    T = net.simulation_steps
+    assert (steps - 1) * e.n_all * R > 2 ** 31 and steps == T
+    origins = list(net.origin_nodes)
+    for nid in origins:
+        net.set_demand_matrix(nid, np.stack([poisson_demand(T, r, base=40.0, peak=80.0) for r in range(R)]))
+    net.run(1, steps)
+    rc, _ = e.error_flags()
+    assert rc == 0
+    model = flatten_network(net)
+    for r in (0, R // 2, R - 1):
+        o = od.Oracle(model, seed=5, replica=r)
+        for nid in origins:
+            o.set_demand(net.nodes[nid].index, poisson_demand(T, r, base=40.0, peak=80.0))
+        o.run(1, steps)
+        assert o.flags() == 0
+        for fname in ALL_FIELDS:
+            mine = e.read_block(LINK_FIELDS[fname][0], 0, steps, rep0=r, rep1=r + 1)[:, :, 0].T
+            cols = e.n_all if LINK_FIELDS[fname][0] < 4 else e.n_links
+            assert np.array_equal(mine[:cols], o.field(fname)[:cols, :steps]), (r, fname)
+        o.close()
+    assert e.read_block(2, steps - 1, steps, rep0=R - 1, rep1=R).sum() > 0
+    net.close()
+
+
 @pytest.mark.parametrize("randomized", [False, True])
 def test_config5_rl_step_2048_envs_full_size(randomized):
     """45_intersections x 2048 envs, option3, 110 env steps of uniform random actions: observations and rewards of four envs
