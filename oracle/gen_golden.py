@@ -527,6 +527,10 @@ for _r in range(4):
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import demand_callables as dc  # noqa: E402
 
+CASES.update({   # the shortest horizons the reference's loop `for t in range(1, simulation_steps)` can run: one step, two steps
+    "edge_T2": lambda: direct_case("edge_T2", EDGE_ADJ, dict(EDGE_PARAMS_SHORT, simulation_steps=2), [0], destination_nodes=[2, 3], seed=4, replica=0),
+    "edge_T3": lambda: direct_case("edge_T3", EDGE_ADJ, dict(EDGE_PARAMS_SHORT, simulation_steps=3), [0], destination_nodes=[2, 3], seed=4, replica=2),
+})
 CASES.update({   # the calling sequence of examples/forky_queues.py:71-118: a front gate narrowed BEFORE the first step, opened at a later one
     "forky_front": lambda: direct_case("forky_front", FORKY_ADJ, dict(FORKY_PARAMS, simulation_steps=420), [0, 4], tf_nodes=[1],
                                        tf_values=[[1, 0, 0.5, 0.5, 0, 1]], seed=8, replica=3,

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full", "i45_prefix", "delft_prefix",
          "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky", "odd_params", "odd_separators", "star8", "edge_window_gt_T", "edge_empty",
-         "butterfly_scA_full", "butterfly_scB_full", "butterfly_scC_full", "one_intersection_full", "two_coordinators_prefix", "spike_callable", "melbourne_callable", "forky_front"]
+         "butterfly_scA_full", "butterfly_scB_full", "butterfly_scC_full", "one_intersection_full", "two_coordinators_prefix", "spike_callable", "melbourne_callable", "forky_front", "edge_T2", "edge_T3"]
 
 
 def _dev_math(op, a, b=None, seed=0):

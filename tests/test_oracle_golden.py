@@ -9,7 +9,7 @@ CASES = ["six_node_full", "nine_full", "long_corridor_full", "small_network_full
          "melbourne_prefix", "nine_meanfield", "six_node_gate", "forky", "nine_replica0", "nine_replica1",
          "nine_replica2", "nine_replica3", "odd_params", "odd_separators", "star8", "edge_window_gt_T", "edge_empty", "rand_nine_a", "rand_nine_b", "rand_delft_a",
          "rand_delft_b", "randnet_i45_a", "randnet_i45_b", "randnet_nine", "butterfly_scA_full", "butterfly_scB_full", "butterfly_scC_full",
-         "one_intersection_full", "two_coordinators_prefix", "spike_callable", "melbourne_callable", "forky_front"]
+         "one_intersection_full", "two_coordinators_prefix", "spike_callable", "melbourne_callable", "forky_front", "edge_T2", "edge_T3"]
 
 
 @pytest.mark.parametrize("case", CASES)
