@@ -2,14 +2,18 @@
 // Included once by pedn_hip.hip (single translation unit, compiled with -ffp-contract=off).
 //
 // Kernels per step t (reference network.py:266-287):
-//   turn_frac_kernel  one workgroup per (dynamic node, 64 replicas): logit route choice -> the node's turning fractions
-//                                                                                      path_finder.py:561-737
 //   node_kernel       one wave per (node slot, 64 replicas), one block per bin of nodes with <= 8 slots in total:
 //                     sending flow of the slot's incoming link, receiving flow of its outgoing link, the node's flow
 //                     distribution through LDS, cumulative counts
 //                                                                 node.py:164-221,230-242,272-300; link.py:216-416
-//   link_kernel       one lane per (corridor = link pair, two replicas): pedestrians, density, fundamental diagram,
-//                     travel time and its moving average                                link.py:133-188; functions.py:112-134
+//   link_kernel_1r    the launch behind it when no node has dynamic fractions: one lane per (corridor = link pair, replica):
+//                     pedestrians, density, fundamental diagram, travel time and its moving average
+//                                                                                       link.py:133-188; functions.py:112-134
+//                     (link_kernel<NS>: the same with two replicas per lane in NS segments of 128 replicas, PEDN_LINK_NS)
+//   link_turn_kernel  the launch behind it otherwise: [turning fractions of t+1, long rows | link update of t, two replicas per
+//                     lane | turning fractions of t+1, short rows | RL observations of t] as independent workgroups
+//   turn_frac_kernel  the turning fractions on their own (first step of an episode): one wave per (row of a dynamic node, 64
+//                     replicas): logit route choice -> the row's turning fractions      path_finder.py:561-737
 // plus the batched RL glue (rl_apply_kernel, rl_observe_kernel), state initialisation and host<->device helpers.
 #pragma once
 #include "pedn_math.hpp"
