@@ -165,22 +165,28 @@ def test_stepping_through_the_last_time_index():
     from pednstream_amd.rl_env import VecPedNetEnv
 
     g = Golden("nine_full")
-    net = build_network(g, n_replicas=64, rng_seed=g.seed)
+    net = build_network(g, n_replicas=256, rng_seed=g.seed)       # 256: enough for the two-chain plan below
     e = net.engine()
     T = net.simulation_steps
     net.run(1, T - 3)
     for t in range(T - 3, T + 1):
         net.network_loading(t)
     model = flatten_network(net)
-    for r in (0, 63):
+    for r in (0, 255):
         o = od.Oracle(model, seed=g.seed, replica=r)
         o.run(1, T + 1)
         for fname in ALL_FIELDS:
             mine = e.read_block(LINK_FIELDS[fname][0], 0, T + 1, rep0=r, rep1=r + 1)[:, :, 0].T
             assert np.array_equal(mine[:e.n_links], o.field(fname)[:e.n_links]), (r, fname)
-    e.reset()
-    net.run(1, T + 1)                               # the same through pedn_run (two halves when the plan says so)
-    assert e.error_flags()[0] == 0
+    last_rows = {f: e.read_block(LINK_FIELDS[f][0], T - 2, T + 1) for f in ALL_FIELDS}
+    for plan in (1, 2):                             # the same through pedn_run, as one chain and as two chains of launches
+        e.set_streams(plan)
+        e.reset()
+        net.run(1, T - 10)
+        assert e.profile_run(T - 10, T + 1)[1] == plan          # the range that ends with step T really ran under that plan
+        assert e.error_flags()[0] == 0
+        for f in ALL_FIELDS:
+            assert np.array_equal(e.read_block(LINK_FIELDS[f][0], T - 2, T + 1), last_rows[f]), (plan, f)
     with pytest.raises(Exception):
         e.run(1, T + 2)
     net.close()
