@@ -89,7 +89,12 @@ def test_largest_single_gpu_batch_melbourne_4608():
     R, steps = 4608, 500                   # element index (t * columns + column) * replicas + replica passes 2^31 at t = 476
     np.random.seed(7)
     net = NetworkEnvGenerator(DATA).create_network("melbourne", verbose=False, n_replicas=R, rng_seed=5)
-    e = net.engine()
+    try:
+        e = net.engine()
+    except RuntimeError as err:          # a GPU with less than 173 GB free cannot hold this batch: that is not a parity failure
+        if "not enough HBM" in str(err):
+            pytest.skip(str(err))
+        raise
     T = net.simulation_steps
     assert (steps - 1) * e.n_all * R > 2 ** 31 and steps == T
     origins = list(net.origin_nodes)
