@@ -98,8 +98,10 @@ struct SlotIn {
 };
 
 // Link.cal_sending_flow (link.py:216-370) incl. get_outflow (:199-214) for t' >= free_flow_tau
+// ci_look = cumulative_inflow[max(0, t' + 1 - tau)] of the link, loaded by the caller (tau from x.att_in as below) so that the load is
+// in flight while the caller draws the receiving side's binomial
 template <bool HIST>
-__device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, uint32_t& fl) {
+__device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, double ci_look, uint32_t& fl) {
   const int RS = v.RS, T1 = v.T1;
   const float nself = x.n_in, nrev = x.n_out, kk = x.k_in, att = x.att_in;
   float dens = P.sep ? kk : (nself + nrev) / P.area32;
@@ -108,7 +110,7 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
   int idx = tp + 1 - tau;
   if (idx < 0) idx = 0;
   float cf = clip01((kk - P.kc32) / P.dk32);  // link.py:282
-  double ff = v.f64[F_CI][at(R64(F_CI, idx), l, v.Lall, RS, r)] - x.co_in;  // the one data-dependent look-back of the common path
+  double ff = ci_look - x.co_in;  // the one data-dependent look-back of the common path (loaded by the caller at row idx)
   if (!(ff > 0.0)) ff = 0.0;
   double bnd = (double)(cf * nself) + (double)(1.0f - cf) * ff;  // link.py:284-288
   double smax = x.front_in * P.kc * P.vf * v.dt;                 // link.py:296
@@ -153,8 +155,15 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
 }
 
 // Link/Separator.cal_receiving_flow[_with_reverse] (link.py:372-416,480-512); the reverse link is the slot's incoming link
-__device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, double s_rev, uint32_t& fl) {
+// rp = Binomial(trunc(num_pedestrians of the reverse link), 0.9) (link.py:381-382), drawn by the caller (recv_reverse_peds)
+__device__ __forceinline__ double recv_reverse_peds(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, uint32_t& fl) {
+  if (P.sep) return 0.0;
   const float nrev = x.n_in;
+  if (nrev < 0.0f) fl |= PEDN_F_NEG_BINOM;
+  RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)tp, 2u};
+  return rng_binomial((long long)nrev, 0.9, key, v.meanfield);
+}
+__device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, double s_rev, double rp, uint32_t& fl) {
   double kjA = P.sep ? P.kj * (P.length * x.sepw_out) : P.kjA;
   int tsw = P.tau_sw;
   double b;
@@ -165,9 +174,6 @@ __device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int
       b = x.co_sw + kjA - x.ci_out;
     }
   } else {
-    if (nrev < 0.0f) fl |= PEDN_F_NEG_BINOM;
-    RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)tp, 2u};
-    double rp = rng_binomial((long long)nrev, 0.9, key, v.meanfield);  // link.py:381-382
     if (tp + 1 - tsw < 0) b = kjA - rp;
     else {
       if (tsw <= 0) fl |= PEDN_F_SAME_STEP;
@@ -720,11 +726,17 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
       ci_prev = x.ci_out;  // cumulative_inflow[t-1] of the outgoing link
       PH(2, x.n_in + x.k_in + x.att_in + (float)(x.co_in + x.s_prev + x.co_sw + x.ci_out + x.r_prev + x.front_in + x.back_out));
-      s_i = early ? 0.0 : send_flow<HIST>(v, Pin, lin, tp, r, x, fl);
+      // the sending flow's look-back cumulative_inflow[t' + 1 - tau] is issued here and the receiving side's binomial (a Philox call,
+      // independent of it) is drawn while it is in flight
+      int idx_s = tp + 1 - __float2int_rn(x.att_in / (float)v.dt);  // link.py:260,274
+      if (idx_s < 0) idx_s = 0;
+      const double ci_look = v.f64[F_CI][at(R64(F_CI, idx_s), lin, Lall, RS, r)];
+      const double rp = recv_reverse_peds(v, Pout, lout, tp, r, x, fl);
+      s_i = early ? 0.0 : send_flow<HIST>(v, Pin, lin, tp, r, x, ci_look, fl);
       PH(3, s_i);
       rowp(v.f64[F_S], R64(F_S, tp), lin, L, RS, r0)[lane] = s_i;  // link.py:268,367
       if (s_i < 0.0) fl |= PEDN_F_NEG_FLOW;
-      r_i = recv_flow(v, Pout, lout, tp, r, x, s_i, fl);
+      r_i = recv_flow(v, Pout, lout, tp, r, x, s_i, rp, fl);
       PH(4, r_i);
       rowp(v.f64[F_R], R64(F_R, tp), lout, L, RS, r0)[lane] = r_i;  // node.py:206
     }
