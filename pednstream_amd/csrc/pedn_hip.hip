@@ -649,7 +649,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // against 35.0 us, melbourne 25.8 against 27.1); PEDN_NODE_WAVES=6|8 overrides
     // with per-replica link parameters (node_kernel<PR>: 28 more live vector registers) the budget of 8 waves costs 2..8 vector
     // spills; at 6 waves there is none and the randomised RL step is 2 % faster (profiles/r03_pr_waves.txt)
-    s->node_waves = 8;
+    // a node of 7 or 8 corridors (the instantiation unrolled for 8): 4..8 vector spills at 8 waves, none at 6
+    s->node_waves = s->max_degree <= 6 ? 8 : 6;
     s->node_waves_pr = 6;
     if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = s->node_waves_pr = atoi(w) == 6 ? 6 : 8;
     // The link update of t and the turning fractions of t+1 share one launch (both only read what node_kernel(t) and earlier

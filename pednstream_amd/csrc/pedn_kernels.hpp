@@ -118,15 +118,23 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
   double orig = s;
   RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)tp, 0u};
   if (s > 0.0) {
+    const bool free_flow = dens <= P.kc32;  // link.py:323
+    double i0 = 0.0, i1 = 0.0, i2 = 0.0, i3 = 0.0;
+    if (free_flow) {
+      const double* in = v.f64[F_IN];
+      i0 = in[at(wrap_idx(tp - tau, T1, fl), l, v.Lall, RS, r)], i1 = in[at(wrap_idx(tp - tau - 1, T1, fl), l, v.Lall, RS, r)];
+      i2 = in[at(wrap_idx(tp - tau - 2, T1, fl), l, v.Lall, RS, r)], i3 = in[at(wrap_idx(tp - tau - 3, T1, fl), l, v.Lall, RS, r)];
+    }
+    // Philox call 0 of the sending binomial needs no data: drawn while the four loads are in flight
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    key.site = 0u;
+    if (!v.meanfield) rng_words(key, 0u, w);
     float rf = clip01(dens / P.kj32);                          // link.py:315
     float p = 0.7f + (float)(0.85 - 0.7) * pedn_powf(rf, 0.8f);     // link.py:317
     bool diffusion_used = false;
-    if (dens <= P.kc32) {  // link.py:323
+    if (free_flow) {
       float F = 1.0f / (1.0f + P.gamma32 * att);
       float G = 1.0f - F;
-      const double* in = v.f64[F_IN];
-      double i0 = in[at(wrap_idx(tp - tau, T1, fl), l, v.Lall, RS, r)], i1 = in[at(wrap_idx(tp - tau - 1, T1, fl), l, v.Lall, RS, r)];
-      double i2 = in[at(wrap_idx(tp - tau - 2, T1, fl), l, v.Lall, RS, r)], i3 = in[at(wrap_idx(tp - tau - 3, T1, fl), l, v.Lall, RS, r)];
       float G2, G3;
       pedn_powf_2_3(G, G2, G3);
       double d = (double)F * i0 + (double)(F * G) * i1 + (double)(F * G2) * i2 + (double)(F * G3) * i3;
@@ -137,10 +145,7 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
         diffusion_used = true;
       }
     }
-    if (!diffusion_used) {  // link.py:336-338,342-344
-      key.site = 0u;
-      s = rng_binomial((long long)floor(s), (double)p, key, v.meanfield);
-    }
+    if (!diffusion_used) s = rng_binomial_w((long long)floor(s), (double)p, key, w, v.meanfield);  // link.py:336-338,342-344
     if (s < 0.0) fl |= PEDN_F_NEG_SENDING;
   }
   if (P.act > 0.0 && s > 1.0) {  // link.py:351-358
@@ -839,8 +844,16 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
 // BiDirectionalFd.__call__ + the travel-time part of Link.update_speeds for one direction and one replica; pure arithmetic
 struct SpeedOut { float spd, tt, lf, att, rs; };
 
+// the speed noise of (link, step, replica) (functions.py:132-133): depends on no simulation state, so callers draw it while
+// their loads are in flight
+__device__ __forceinline__ double speed_noise(const DevView& v, const LinkP& P, int l, int t, int r) {
+  if (!(P.noise > 0.0) || v.meanfield) return 0.0;
+  RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)t, 3u};
+  return P.noise * rng_z(key);
+}
+
 __device__ __forceinline__ SpeedOut speed_calc(const DevView& v, const LinkP& P, int l, int t, int r, float ks, float ko,
-                                               float rsum_prev, float tt_old) {
+                                               float rsum_prev, float tt_old, double nz) {
   float ke = P.sep ? ks : ks + (float)P.bi * ko;  // functions.py:113
   bool is64;  // true: the speed is a Python float (binary64) at this point, false: np.float32
   double v64 = 0.0;
@@ -858,12 +871,7 @@ __device__ __forceinline__ SpeedOut speed_calc(const DevView& v, const LinkP& P,
     is64 = false;
     if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }  // Python max(0, x) returns the int 0
   }
-  if (P.noise > 0.0) {  // functions.py:132-133
-    double nz = 0.0;
-    if (!v.meanfield) {
-      RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)t, 3u};
-      nz = P.noise * rng_z(key);
-    }
+  if (P.noise > 0.0) {  // functions.py:132-133, nz = speed_noise(...)
     if (is64) v64 = v64 + nz;
     else v32 = v32 + (float)nz;
   }
@@ -926,6 +934,15 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
     if (!Pa.sep && !(bua == bua)) ga[s] = ld2(v.back, (size_t)a * RS + r);
     if (!Pb.sep && !(bub == bub)) gb[s] = ld2(v.back, (size_t)b * RS + r);
   }
+  // ---- the noise draws need none of the loads
+  double nza[NS][2], nzb[NS][2];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      nza[s][j] = speed_noise(v, Pa, a, t, r0 + 128 * s + j);
+      nzb[s][j] = speed_noise(v, Pb, b, t, r0 + 128 * s + j);
+    }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int r = r0 + 128 * s;
@@ -943,8 +960,8 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
       // a separator width held as np.float64 turns the division into binary64 (PEDN_W_SEP_NUMPY)
       ka[j] = (Pa.sep && fav[j] != 0.0) ? (float)((double)na[j] / (Pa.length * wav[j])) : na[j] / (float)(Pa.length * wav[j]);
       kb[j] = (Pb.sep && fbv[j] != 0.0) ? (float)((double)nb[j] / (Pb.length * wbv[j])) : nb[j] / (float)(Pb.length * wbv[j]);
-      sa[j] = speed_calc(v, Pa, a, t, r + j, ka[j], kb[j], rsav[j], oav[j]);
-      sb[j] = speed_calc(v, Pb, b, t, r + j, kb[j], ka[j], rsbv[j], obv[j]);
+      sa[j] = speed_calc(v, Pa, a, t, r + j, ka[j], kb[j], rsav[j], oav[j], nza[s][j]);
+      sb[j] = speed_calc(v, Pb, b, t, r + j, kb[j], ka[j], rsbv[j], obv[j], nzb[s][j]);
     }
     // ---- stores: all at the end (issued as their values appear, between the two speed computations, the launch is 0.5 us slower)
     st2(v.f32[G_N], at(R32(G_N, t), a, L, RS, r), na[0], na[1]);
@@ -974,18 +991,24 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
 // inside node_kernel -- the later of a corridor's two end waves updated the corridor, PEDN_FUSE_LINK=1.  Parity-green and never
 // faster with write-through hand-off (profiles/r02_last_arriver.txt); with the hand-off the memory model asks for -- agent-scope
 // release / acquire fences = L2 write-back and invalidate per wave -- 18 x slower (profiles/r03_last_arriver.txt).  Removed.)
-template <bool HIST>
+template <bool HIST, bool EARLY_NOISE>
 __device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& Pa, const LinkP& Pb, int a, int b, int t, int r,
-                                                double da, double db, float pa, float pb) {
+                                                double ina, double outa, double inb, double outb, float pa, float pb) {
   const int RS = v.RS, L = v.L;
   const bool win = t >= v.W;
-  const float na = (float)((double)pa + da), nb = (float)((double)pb + db);
+  // EARLY_NOISE: the draws run under the caller's loads (inside link_turn_kernel: -0.4 us per launch; the stand-alone launch over
+  // shared parameters is 0.3 us faster with the draws where the speed is computed -- profiles/r03_noise_under_loads.txt)
+  double nza = 0.0, nzb = 0.0;
+  if (EARLY_NOISE) { nza = speed_noise(v, Pa, a, t, r); nzb = speed_noise(v, Pb, b, t, r); }
+  const float na = (float)((double)pa + (ina - outa)), nb = (float)((double)pb + (inb - outb));
   const double wa = Pa.sep ? v.sepw[(size_t)a * RS + r] : Pa.width, wb = Pb.sep ? v.sepw[(size_t)b * RS + r] : Pb.width;
   const float ka = (Pa.sep && v.sepnp[(size_t)a * RS + r] != 0.0) ? (float)((double)na / (Pa.length * wa)) : na / (float)(Pa.length * wa);
   const float kb = (Pb.sep && v.sepnp[(size_t)b * RS + r] != 0.0) ? (float)((double)nb / (Pb.length * wb)) : nb / (float)(Pb.length * wb);
   const float oa = win ? v.f32[G_TT][at(R32(G_TT, t - v.W), a, L, RS, r)] : 0.0f, ob = win ? v.f32[G_TT][at(R32(G_TT, t - v.W), b, L, RS, r)] : 0.0f;
-  const SpeedOut sa = speed_calc(v, Pa, a, t, r, ka, kb, v.rsum[(size_t)a * RS + r], oa);
-  const SpeedOut sb = speed_calc(v, Pb, b, t, r, kb, ka, v.rsum[(size_t)b * RS + r], ob);
+  if (!EARLY_NOISE) nza = speed_noise(v, Pa, a, t, r);
+  const SpeedOut sa = speed_calc(v, Pa, a, t, r, ka, kb, v.rsum[(size_t)a * RS + r], oa, nza);
+  if (!EARLY_NOISE) nzb = speed_noise(v, Pb, b, t, r);
+  const SpeedOut sb = speed_calc(v, Pb, b, t, r, kb, ka, v.rsum[(size_t)b * RS + r], ob, nzb);
   // recorded width (link.py:188 / :451-452): the separator width, or the back gate -- one scalar load when every replica shares it
   const double bua = v.back_u[a], bub = v.back_u[b];
   const double ga = Pa.sep ? wa : (bua == bua ? bua : v.back[(size_t)a * RS + r]), gb = Pb.sep ? wb : (bub == bub ? bub : v.back[(size_t)b * RS + r]);
@@ -1011,9 +1034,9 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
   const CorrRec& C = v.corr_rec[p];
   const int a = C.a, b = C.b;
   const LinkP Pa = lane_params<PR>(v, C.Pa, a, r), Pb = lane_params<PR>(v, C.Pb, b, r);
-  const double da = v.f64[F_IN][at(R64(F_IN, t), a, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), a, Lall, RS, r)];
-  const double db = v.f64[F_IN][at(R64(F_IN, t), b, Lall, RS, r)] - v.f64[F_OUT][at(R64(F_OUT, t), b, Lall, RS, r)];
-  link_update_one<HIST>(v, Pa, Pb, a, b, t, r, da, db, v.f32[G_N][at(R32(G_N, t - 1), a, L, RS, r)], v.f32[G_N][at(R32(G_N, t - 1), b, L, RS, r)]);
+  link_update_one<HIST, PR>(v, Pa, Pb, a, b, t, r, v.f64[F_IN][at(R64(F_IN, t), a, Lall, RS, r)], v.f64[F_OUT][at(R64(F_OUT, t), a, Lall, RS, r)],
+                        v.f64[F_IN][at(R64(F_IN, t), b, Lall, RS, r)], v.f64[F_OUT][at(R64(F_OUT, t), b, Lall, RS, r)],
+                        v.f32[G_N][at(R32(G_N, t - 1), a, L, RS, r)], v.f32[G_N][at(R32(G_N, t - 1), b, L, RS, r)]);
 }
 
 template <int NS, bool HIST>
@@ -1115,7 +1138,7 @@ __device__ __forceinline__ void rl_observe_body(const DevView& v, const RlView& 
         const double wa = P.sep ? v.sepw[(size_t)l * RS + r] : P.width, wb = Pr.sep ? v.sepw[(size_t)P.rev * RS + r] : Pr.width;
         const float ka = (P.sep && v.sepnp[(size_t)l * RS + r] != 0.0) ? (float)((double)na / (P.length * wa)) : na / (float)(P.length * wa);
         const float kb = (Pr.sep && v.sepnp[(size_t)P.rev * RS + r] != 0.0) ? (float)((double)nb / (Pr.length * wb)) : nb / (float)(Pr.length * wb);
-        const SpeedOut sa = speed_calc(v, P, l, t, r, ka, kb, 0.0f, 0.0f), sb = speed_calc(v, Pr, P.rev, t, r, kb, ka, 0.0f, 0.0f);
+        const SpeedOut sa = speed_calc(v, P, l, t, r, ka, kb, 0.0f, 0.0f, speed_noise(v, P, l, t, r)), sb = speed_calc(v, Pr, P.rev, t, r, kb, ka, 0.0f, 0.0f, speed_noise(v, Pr, P.rev, t, r));
         tt_l = sa.tt;
         tt_r = sb.tt;
         spd = sa.spd;

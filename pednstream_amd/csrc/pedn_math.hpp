@@ -165,13 +165,11 @@ __device__ inline double rng_z(const RngKey& k) {
   return (double)((int)s - 262140) * 0x1.3988e1409212ep-16;
 }
 
-__device__ inline double rng_binomial(long long n, double p, const RngKey& k, int meanfield) {
+// rng_binomial with Philox call 0 of the key already drawn into w (by a caller that had a load in flight to draw it under)
+__device__ inline double rng_binomial_w(long long n, double p, const RngKey& k, uint32_t (&w)[4], int meanfield) {
   if (n <= 0 || p <= 0.0) return 0.0;
   if (meanfield) return floor((double)n * p);
   if (p >= 1.0) return (double)n;
-  // both branches start from Philox call 0: drawn once, ahead of the branch (lanes of one wave usually take both)
-  uint32_t w[4];
-  rng_words(k, 0u, w);
   if (n <= 16) {
     const uint32_t thr = (uint32_t)floor(p * 65536.0);
     const int nn = (int)n;
@@ -199,6 +197,16 @@ __device__ inline double rng_binomial(long long n, double p, const RngKey& k, in
   if (x < 0.0) x = 0.0;
   if (x > (double)n) x = (double)n;
   return x;
+}
+
+__device__ inline double rng_binomial(long long n, double p, const RngKey& k, int meanfield) {
+  if (n <= 0 || p <= 0.0) return 0.0;
+  if (meanfield) return floor((double)n * p);
+  if (p >= 1.0) return (double)n;
+  // both branches start from Philox call 0: drawn once, ahead of the branch (lanes of one wave usually take both)
+  uint32_t w[4];
+  rng_words(k, 0u, w);
+  return rng_binomial_w(n, p, k, w, 0);
 }
 
 }  // namespace pedn

@@ -51,7 +51,9 @@ def kernel_metadata(tmp_path):
 #   pattern -> (max VGPRs = waves per SIMD it must keep, max LDS bytes = workgroups per CU, may spill scalar registers?)
 BUDGETS = {
     # shared link parameters, classic node model: 8 waves per SIMD; scalar spills go to VGPR lanes (cheap), vector spills to scratch
-    r"node_kernel<false, 8, false, (true|false), \d>": (64, None, True),
+    r"node_kernel<false, 8, false, (true|false), 6>": (64, None, True),
+    # networks with a node of 7 or 8 corridors (loops unrolled for 8): launched at 6 waves per SIMD (pedn_create: node_waves)
+    r"node_kernel<false, 6, false, (true|false), 8>": (80, None, True),
     # per-replica link parameters (randomised RL resets, ensembles): launched at 6 waves per SIMD (pedn_create: node_waves_pr) --
     # at 8 it spilled 2..8 vector registers; no spill of either kind, 6 waves (<= 80 VGPRs)
     r"node_kernel<true, 6, false, (true|false), \d>": (80, None, False),
@@ -61,7 +63,7 @@ BUDGETS = {
     # (the OBS instantiation was at 131-133 VGPRs / 42.5 KB = 3 until the parts shared one LDS buffer)
     r"link_turn_kernel<(true|false), (true|false), 1, (true|false)>": (128, 40960, True),
     r"turn_frac_kernel<(true|false), (true|false)>": (128, 40960, True),
-    r"link_kernel<1, (true|false)>": (72, None, True),          # 7 waves per SIMD
+    r"link_kernel<1, (true|false)>": (80, None, True),          # 6 waves per SIMD (a diagnostic: PEDN_LINK_NS=1)
     r"link_kernel_1r<(true|false), (true|false)>": (64, None, False),    # one replica per lane: per-replica parameters, or PEDN_LINK_NS=0
     r"rl_observe_kernel<(true|false)>": (64, 8192, False),
     r"rl_apply_kernel": (64, None, False),
