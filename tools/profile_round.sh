@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the tracked measurement files of a round on the GPU box (run through gpurun from the repo root):
 #
-#   gpurun --timeout 1150 -- 'bash tools/profile_round.sh r02 [part]'      part: all (default) | trace | bench | extras
+#   gpurun --timeout 1150 -- 'bash tools/profile_round.sh r02 [part]'      part: all (default) | trace | bench | extras | rl
 #
 # writes gpurun_out/profiles_out/<tag>_*; copy those into profiles/ afterwards.  Kernel trace and every PMC group are
 # separate rocprofv3 runs of the same bench command (a --pmc run must not be combined with other trace domains).
@@ -40,6 +40,13 @@ if [ "$PART" = all ] || [ "$PART" = trace ]; then
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cw -- python3 $R/tools/pmc_calibrate.py > $O/cw.log 2>&1
   profile "" --network melbourne
   profile _delft --network delft
+  # config #5: per-kernel durations of the batched RL step, plain and after reset(options={'randomize': True})
+  rm -rf $O/ktrl $O/ktrl2
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrl -- python3 $R/bench.py --rl --network 45_intersections --replicas 2048 > $O/ktrl.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrl2 -- python3 $R/bench.py --rl --randomize --network 45_intersections --replicas 2048 > $O/ktrl2.log 2>&1
+  cp $O/ktrl/*/*_kernel_stats.csv $P/${TAG}_rl_kernel_stats.csv
+  cp $O/ktrl2/*/*_kernel_stats.csv $P/${TAG}_rl_randomized_kernel_stats.csv
+  rm -rf $O/ktrl $O/ktrl2
   # practical ceiling of a coalesced stream (8- / 16-byte lanes, scattered chunks): per-launch durations of device_math_kernel
   rocprofv3 --kernel-trace --output-format csv -d $O/sc -- python3 $R/tools/stream_ceiling.py > $O/sc.log 2>&1
   python3 - "$O/sc" > $P/${TAG}_stream_ceiling.txt <<'PY'
@@ -52,6 +59,15 @@ for r, lab in zip(rows, labels):
     print(f"  {lab:32s} {us:9.1f} us  {1.5 * 2**30 / us / 1e6:7.2f} TB/s")
 PY
   rm -rf $O/kt* $O/pf* $O/pw* $O/sq1* $O/sq2* $O/sq3* $O/sq4* $O/cf $O/cw $O/sc      # the raw traces are large; the summaries above are what is kept
+fi
+if [ "$PART" = rl ]; then      # only the RL kernel statistics of the trace part
+  rm -rf $O/ktrl $O/ktrl2
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrl -- python3 $R/bench.py --rl --network 45_intersections --replicas 2048 > $O/ktrl.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrl2 -- python3 $R/bench.py --rl --randomize --network 45_intersections --replicas 2048 > $O/ktrl2.log 2>&1
+  cp $O/ktrl/*/*_kernel_stats.csv $P/${TAG}_rl_kernel_stats.csv
+  cp $O/ktrl2/*/*_kernel_stats.csv $P/${TAG}_rl_randomized_kernel_stats.csv
+  rm -rf $O/ktrl $O/ktrl2
+  head -4 $P/${TAG}_rl_kernel_stats.csv $P/${TAG}_rl_randomized_kernel_stats.csv | cut -c1-150
 fi
 cd $R
 if [ "$PART" = all ] || [ "$PART" = bench ]; then
