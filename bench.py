@@ -15,10 +15,10 @@ value = links x replicas(all ranks) x K / wall-seconds (max over ranks) of the t
 HBM before the region starts.  The line also carries
   roofline     dominant kernel (node_kernel).  `traffic` = memory-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
                passes of this same command, run as child processes BEFORE this process touches the GPU (N = 1; the committed
-               profiles/ summary otherwise).  `achieved` / `frac` = those MOVED bytes / the launch's duration (dispatch timestamps)
-               vs 8 TB/s when the passes succeeded; the contract figure (ALGORITHMIC bytes per launch, 164 B per link-update, /
-               the same duration) is `achieved_algorithmic` / `frac_algorithmic` -- and is what `achieved` / `frac` fall back to
-               without live counters (`basis` says which).  `working_set_bytes_per_step` + `fits_infinity_cache`: whether "hbm"
+               profiles/ summary of the same workload otherwise).  `achieved` / `frac` = those MOVED bytes / the launch's duration
+               (dispatch timestamps) vs 8 TB/s; the contract figure (ALGORITHMIC bytes per launch, 164 B per link-update, / the same
+               duration) is `achieved_algorithmic` / `frac_algorithmic` -- and is what `achieved` / `frac` fall back to for a workload
+               without counter passes, live or committed (`basis` says which of the three).  `working_set_bytes_per_step` + `fits_infinity_cache`: whether "hbm"
                means HBM for this batch; the whole step is `whole_step_frac` (212 B per link-update) / `whole_step_frac_counter`
   cpu_baseline the C restatement under oracle/ timed on this host's cores (1 thread and all cores, CPU model stated) on a
                bounded sample of the same workload + the derived reference-Python equivalent (profiles/cpu_calibration.json)
@@ -419,8 +419,11 @@ def measure(args, network, dist, rank, local_rank, world):
     # `achieved` / `frac`: bytes the memory side MOVED for the launch (FETCH_SIZE + WRITE_SIZE) over its duration when the PMC passes
     # of this run succeeded -- the kernel moves fewer bytes than the contract counts (shared widths and static fractions are scalar
     # loads, cumulative_*[t-1] is reused), so the contract figure over the same duration would overstate what the memory system did;
-    # that figure stays beside it as `achieved_algorithmic` / `frac_algorithmic`.  Without live counters both pairs are the contract's.
-    achieved = traffic / (node_ms * 1e-3) / 1e9 if live else achieved_alg
+    # that figure stays beside it as `achieved_algorithmic` / `frac_algorithmic`.
+    # Without live passes (N > 1, --no-live-traffic) the per-launch bytes of the committed passes of the same workload stand in -- the
+    # traffic of a launch does not vary from run to run (112.4..112.9 MB over the round) -- and `basis` says so; with neither, both
+    # pairs are the contract's.
+    achieved = traffic / (node_ms * 1e-3) / 1e9 if traffic is not None else achieved_alg
     working_set = None if traffic is None or traffic2 is None else (traffic + traffic2) * chains
     mdl = e.model
     n_dyn_turns = int(np.diff(mdl["node_turn_ptr"])[np.asarray(mdl["node_dyn"]) > 0].sum())     # +8 B each per replica
@@ -436,7 +439,9 @@ def measure(args, network, dist, rank, local_rank, world):
         "roofline": {"bound": "hbm", "kernel": "node_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "basis": ("bytes moved: rocprofv3 FETCH_SIZE + WRITE_SIZE of this run per launch / the launch's duration" if live else
-                               "algorithmic bytes per launch / the launch's duration (no live counter passes in this run)"),
+                               "bytes moved per launch in the COMMITTED rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this workload (traffic_source) / "
+                               "this run's launch duration (no live counter passes in this run)" if traffic is not None else
+                               "algorithmic bytes per launch / the launch's duration (no counter passes for this workload, live or committed)"),
                      "achieved_algorithmic": achieved_alg, "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "frac_counter": None if traffic is None else traffic / (node_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
