@@ -582,6 +582,10 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         cr.push_back(c);
       }
     v.n_pairs_corr = (int)cr.size();
+    v.pairs_adj = 1;
+    for (size_t p = 0; p < cr.size(); ++p)
+      if (cr[p].a != 2 * (int)p || cr[p].b != 2 * (int)p + 1) v.pairs_adj = 0;
+    if (const char* f = getenv("PEDN_PAIRS_ADJ")) if (atoi(f) == 0) v.pairs_adj = 0;   // diagnostic: always through the record
     TRY(upload(s, cr.data(), cr.size(), &v.corr_rec));
   }
   {  // bin nodes into blocks of 8 waves: first-fit over the nodes ordered by (expected load, slot count) decreasing, so that

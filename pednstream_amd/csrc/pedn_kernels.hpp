@@ -908,7 +908,9 @@ __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
   const int r0 = v.sub0 + (lh / 64) * (128 * NS) + (lh % 64) * 2;  // first replica of segment 0; segment s starts 128 s further
   if (p >= v.n_pairs_corr) return;
   const CorrRec& C = v.corr_rec[p];  // wave-uniform
-  const int a = C.a, b = C.b;
+  // the rows of both directions are addressed from p alone where the model allows it (DevView.pairs_adj): their loads are then in
+  // flight while the record -- a dependent, cache-cold fetch at the start of a launch -- arrives
+  const int a = v.pairs_adj ? 2 * p : C.a, b = v.pairs_adj ? 2 * p + 1 : C.b;
   const LinkP& Pa = C.Pa;
   const LinkP& Pb = C.Pb;
   const bool win = t >= v.W;
@@ -1032,7 +1034,7 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
   const int r = v.sub0 + (int)(gid % (size_t)v.subRS);
   if (p >= v.n_pairs_corr) return;
   const CorrRec& C = v.corr_rec[p];
-  const int a = C.a, b = C.b;
+  const int a = v.pairs_adj ? 2 * p : C.a, b = v.pairs_adj ? 2 * p + 1 : C.b;   // see link_body
   const LinkP Pa = lane_params<PR>(v, C.Pa, a, r), Pb = lane_params<PR>(v, C.Pb, b, r);
   link_update_one<HIST, PR>(v, Pa, Pb, a, b, t, r, v.f64[F_IN][at(R64(F_IN, t), a, Lall, RS, r)], v.f64[F_OUT][at(R64(F_OUT, t), a, Lall, RS, r)],
                         v.f64[F_IN][at(R64(F_IN, t), b, Lall, RS, r)], v.f64[F_OUT][at(R64(F_OUT, t), b, Lall, RS, r)],

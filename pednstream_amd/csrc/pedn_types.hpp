@@ -96,6 +96,8 @@ struct DevView {
   // flow looks back an unbounded, data-dependent number of steps into them), the others are rings of mask + 1 rows.
   int32_t m64[7], m32[6];
   int32_t hist;
+  int32_t pairs_adj;  // 1: corridor p is the links (2p, 2p + 1) -- the reference creates the two directions of an edge one after the other --
+                      // so the link update forms its row addresses from p alone, without waiting for the corridor's record
   int32_t sub0, subRS;  // replicas [sub0, sub0 + subRS) are this launch's share (the whole batch, or one half of it per stream)
   // gater actions applied inside node_kernel (pedn_rl_step, gater-only agent sets): row-major [R][rl_A] widths, NaN = no action
   const double* rl_actions;

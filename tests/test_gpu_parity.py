@@ -184,7 +184,9 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
 
-    def history(fuse, waves, stepwise, general="0", lds_limit="64", md="6", link_ns="0", heavy="2"):
+    def history(fuse, waves, stepwise, general="0", lds_limit="64", md="6", link_ns="0", heavy="2", pairs_adj="1"):
+        monkeypatch.setenv("PEDN_PAIRS_ADJ", pairs_adj)        # 0: the link update takes its two link ids from the corridor's record (models whose
+                                                               # directions are not numbered 2p, 2p + 1), 1: from the corridor index where the model allows
         monkeypatch.setenv("PEDN_TF_HEAVY_GROUPS", heavy)      # which rows of dynamic nodes go in front of the link update inside link_turn_kernel
         monkeypatch.setenv("PEDN_LINK_NS", link_ns)           # stand-alone link update: 0 one replica per lane, 1 | 2 two replicas in 1 | 2 segments
         monkeypatch.setenv("PEDN_FUSE_TP", fuse)
@@ -214,7 +216,8 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
     for variant in (("1", "6", False), ("0", "8", False), ("1", "8", True), ("1", "8", False, "3", "64"), ("0", "8", False, "1", "1"),
                     ("1", "8", True, "0", "0"), ("1", "8", False, "0", "64", "8"), ("1", "6", False, "0", "64", "8"),
                     ("0", "8", False, "0", "64", "6", "1"), ("0", "8", True, "0", "64", "6", "2"), ("1", "8", False, "0", "64", "6", "2"),
-                    ("1", "8", False, "0", "64", "6", "0", "0"), ("1", "8", True, "0", "64", "6", "0", "100")):
+                    ("1", "8", False, "0", "64", "6", "0", "0"), ("1", "8", True, "0", "64", "6", "0", "100"),
+                    ("1", "8", False, "0", "64", "6", "0", "2", "0"), ("0", "8", True, "0", "64", "6", "0", "2", "0")):
         got = history(*variant)
         for f in ALL_FIELDS:
             assert np.array_equal(ref[f], got[f]), (variant, f)
