@@ -370,13 +370,22 @@ def measure(args, network, dist, rank, local_rank, world):
 
     n_prof = min(40, max(8, args.steps // 8))
     (tf_ms, node_ms, link_ms), chains = profile(n_prof)
+    plan = e.plan_info()
+    owner = plan["link_update_by_next_node_kernel"]
+    if owner:
+        # owner-wave plan: node_kernel<LU>(t + 1) performs the link update of t; the range's ONE trailing link_kernel per chain is
+        # amortised over its steps.  The dominant kernel then carries the whole step's contract bytes.
+        link_ms = link_ms / n_prof
+    node_kernel_bytes = BYTES_PER_LINK_UPDATE if owner else NODE_KERNEL_BYTES
     one_chain = None
     if chains == 2 and not args.no_extra:
         # the same kernels launched over the whole batch, one chain on one stream: what a launch achieves on its own
         e.set_streams(1)
         (tf1, node1, link1), _ = profile(n_prof)
+        if owner:
+            link1 = link1 / n_prof
         e.set_streams(2)
-        one_chain = {"avg_launch_ms": float(node1), "frac": NODE_KERNEL_BYTES * L * R / (node1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        one_chain = {"avg_launch_ms": float(node1), "frac": node_kernel_bytes * L * R / (node1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "other_kernels_ms": {"link_kernel(+turn_frac of t+1)": float(link1), "turn_frac_kernel(stand-alone)": float(tf1)},
                      "whole_step_frac": BYTES_PER_LINK_UPDATE * L * R / ((node1 + link1 + tf1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "note": "diagnostic: pedn_set_streams(1), every launch covers all replicas and runs alone"}
@@ -401,7 +410,7 @@ def measure(args, network, dist, rank, local_rank, world):
                     "whole_step_frac_wall": BYTES_PER_LINK_UPDATE * L * R / (wall2 / args.steps) / 1e9 / HBM_PEAK_GBS}
 
     total_lu = L * R * world * args.steps
-    node_bytes = NODE_KERNEL_BYTES * L * R // chains          # one launch covers R / chains replicas
+    node_bytes = node_kernel_bytes * L * R // chains          # one launch covers R / chains replicas
     step_bytes = BYTES_PER_LINK_UPDATE * L * R
     # time the machine spends on one step of all replicas: one chain -> the sum of its launches (gaps excluded); two chains ->
     # their launches overlap, so the device time of the timed region (HIP events around it) per step
@@ -454,7 +463,8 @@ def measure(args, network, dist, rank, local_rank, world):
                      "note": ("run() launches the two halves of the replicas as two chains on two streams: `achieved` / `frac` are per launch "
                               "(R / 2 replicas) while the other chain's launches share the machine; the machine-level figure is whole_step_frac"
                               if chains == 2 else "one chain of launches"),
-                     "algorithmic_bytes_per_launch": node_bytes, "algorithmic_bytes_per_link_update": NODE_KERNEL_BYTES,
+                     "algorithmic_bytes_per_launch": node_bytes, "algorithmic_bytes_per_link_update": node_kernel_bytes,
+                     "launch_plan": plan,
                      "avg_launch_ms": float(node_ms),
                      "other_kernels_ms": {"link_kernel(+turn_frac of t+1)": float(link_ms), "turn_frac_kernel(stand-alone)": float(tf_ms)},
                      "second_launch_traffic": traffic2,

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PEDN_ABI_VERSION 2
+#define PEDN_ABI_VERSION 3
 #define PEDN_ALL (-1)
 #define PEDN_MAX_DEGREE 8 /* incident corridor slots per node handled by the node kernel */
 
@@ -191,7 +191,10 @@ int pedn_get_widths(pedn_sim* sim, int32_t which, double* values);
  * arrays have T+1 entries like these, so t = T is a valid step -- the batched RL env takes it.  Behind step T no turning fractions
  * of T+1 are prepared: the per-step tables end at T.) */
 int pedn_step(pedn_sim* sim, int32_t t);
-/* steps t0 .. t1-1 enqueued back to back, t1 <= T+1; asynchronous */
+/* steps t0 .. t1-1 enqueued back to back, t1 <= T+1; asynchronous.  Same results as t1 - t0 calls of pedn_step, under the launch
+ * plan the engine picked for the model (pedn_plan_info): for a model without device-computed turning fractions the slot waves of
+ * step t + 1's node kernel perform Network.update_link_states(t) (network.py:257-264) themselves -- ONE launch per step, plus one
+ * link-update launch for the last step of the range, so every history row of steps < t1 is complete when the call's work is. */
 int pedn_run(pedn_sim* sim, int32_t t0, int32_t t1);
 int pedn_synchronize(pedn_sim* sim);
 /* synchronises; flags[n_replicas] may be NULL; returns the OR over replicas (>= 0) or a negative code */
@@ -233,6 +236,11 @@ int pedn_profile_timeline(pedn_sim* sim, int32_t t0, int32_t t1, float* out, int
 /* launch plan of pedn_run for long ranges: 1 = one chain of launches on the engine's stream, 2 = the two halves of the
  * replicas as two chains on two streams (the default from 1024 replicas; replicas are independent, results are the same) */
 int pedn_set_streams(pedn_sim* sim, int32_t n);
+/* The launch plan of pedn_run: info[0] = chains (1 | 2), info[1] = 1 when the link update is performed by the next step's node kernel
+ * (one launch per step), info[2] = streams created until one was found that overlaps with the engine's stream (0: not probed yet;
+ * the runtime may map two streams onto one hardware queue, which would serialise the chains), info[3] = duration in microseconds of
+ * the probe's two concurrent 300 us kernels on the pair kept (~300: they overlap, ~600: they do not); n = entries of info (>= 4). */
+int pedn_plan_info(pedn_sim* sim, int32_t* info, int32_t n);
 
 /* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */
 int pedn_reset(pedn_sim* sim);

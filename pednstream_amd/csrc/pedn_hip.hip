@@ -31,6 +31,9 @@ struct pedn_sim {
   int device = 0;
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
   int node_waves = 8, node_waves_pr = 6;  // register budget of node_kernel (waves per SIMD) with shared / per-replica link parameters, see pedn_create
+  int lu_waves = 8, lu_waves_pr = 6;      // the same for the instantiation that performs the link update (node_kernel<LU>)
+  int link_owner = 0;  // pedn_run: node_kernel(t + 1)'s slot waves perform the link update of t (one launch per step), PEDN_LINK_OWNER
+  int link_pending = -1;  // owner-wave plan: step whose link update has not been performed yet, -1 none
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
   // The link update as a launch of its own runs one replica per lane (link_kernel_1r: 42-47 VGPRs, 8 waves per SIMD; melbourne x 1024
   // 12.3-12.6 against 12.7-13.1 us with two replicas per lane, profiles/r03_link_kernel_variants.txt); inside link_turn_kernel, whose
@@ -41,6 +44,8 @@ struct pedn_sim {
   size_t node_lds = 0;    // dynamic LDS bytes of node_kernel
   hipStream_t stream2 = nullptr;   // second half of the replicas in pedn_run (two_streams)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int streams_probed = 0, stream_probe_attempts = 0;   // warm_second_stream: stream2 was checked to overlap with stream
+  float stream_probe_ms = 0.0f;
   int two_streams = 0;    // pedn_run launches the two halves of the batch on two streams (replicas are independent)
   int second_launch = 0;  // launch_step: a launch followed node_kernel
   int fuse_tp = 0;     // the link update and the next step's turn probabilities share one launch (launch_step)
@@ -151,6 +156,25 @@ static int stage_commit(pedn_sim* s, pedn_sim::Stage* st) {
 
 // The first launch on a stream and the first cross-stream wait cost the runtime ~0.2 ms (queue creation, signal set-up): pay
 // that when the two-chain plan is chosen, not inside the first pedn_run that uses it.
+// The two chains only pay off when the two streams are served by DIFFERENT hardware queues.  The runtime maps streams onto a few
+// queues (GPU_MAX_HW_QUEUES, 4 by default) and, in a process that holds other streams already -- torch + RCCL under the launcher --
+// handed both of the engine's streams the same one: the chains then run one behind the other (melbourne x 1024 30.3 -> 39.0 us per
+// step, delft 42.8 -> 64.8, profiles/r04_stream_queues.txt).  So the pairing is probed, not assumed: a 300 us spin on each stream,
+// timed together; while they do not overlap another candidate for stream2 is created (the rejected ones stay alive until the
+// search ends, so that the runtime moves on to its other queues).
+static int probe_overlap(pedn_sim* s, hipStream_t second, float* ms) {
+  HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
+  HIP_TRY(s, hipStreamWaitEvent(second, s->ev_fork, 0));
+  HIP_TRY(s, hipEventRecord(s->ev0, s->stream));
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s->stream, 30000ull);   // ticks of the constant 100 MHz clock
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, second, 30000ull);
+  HIP_TRY(s, hipEventRecord(s->ev_join, second));
+  HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
+  HIP_TRY(s, hipEventRecord(s->ev1, s->stream));
+  HIP_TRY(s, hipEventSynchronize(s->ev1));
+  HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
+  return PEDN_OK;
+}
 static int warm_second_stream(pedn_sim* s) {
   HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
   HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
@@ -158,7 +182,26 @@ static int warm_second_stream(pedn_sim* s) {
   HIP_TRY(s, hipEventRecord(s->ev_join, s->stream2));
   HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return PEDN_OK;
+  if (s->streams_probed) return PEDN_OK;
+  s->streams_probed = 1;
+  if (const char* f = getenv("PEDN_STREAM_PROBE")) if (atoi(f) == 0) return PEDN_OK;
+  std::vector<hipStream_t> rejected;
+  int rc = PEDN_OK;
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    float ms = 0.0f;
+    rc = probe_overlap(s, s->stream2, &ms);   // the first pass pays for whatever the runtime sets up lazily
+    if (rc == PEDN_OK) rc = probe_overlap(s, s->stream2, &ms);
+    if (rc != PEDN_OK) break;
+    s->stream_probe_ms = ms;
+    s->stream_probe_attempts = attempt + 1;
+    if (ms < 0.45f) break;        // overlapped: 0.3 ms + overheads; one behind the other: 0.6 ms
+    hipStream_t next = nullptr;
+    if (hipStreamCreateWithFlags(&next, hipStreamNonBlocking) != hipSuccess) break;   // keep what we have
+    rejected.push_back(s->stream2);
+    s->stream2 = next;
+  }
+  for (hipStream_t x : rejected) hipStreamDestroy(x);
+  return rc;
 }
 
 static int reset_state(pedn_sim* s) {
@@ -657,6 +700,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     s->node_waves = s->max_degree <= 6 ? 8 : 6;
     s->node_waves_pr = 6;
     if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = s->node_waves_pr = atoi(w) == 6 ? 6 : 8;
+    s->lu_waves = s->node_waves; s->lu_waves_pr = s->node_waves_pr;
+    if (const char* w = getenv("PEDN_LU_WAVES")) s->lu_waves = s->lu_waves_pr = atoi(w) == 6 ? 6 : 8;
     // The link update of t and the turning fractions of t+1 share one launch (both only read what node_kernel(t) and earlier
     // launches wrote); PEDN_FUSE_TP=0 gives the fractions a launch of their own in front of node_kernel(t+1).
     s->fuse_tp = 1;
@@ -668,8 +713,15 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // with dynamic turning-fraction rows from 1024 replicas -- their second launch is few long waves at 4 waves per SIMD, and the
     // other half's node_kernel fills the machine meanwhile (delft x 1024: 51.7 -> 45.3 us per step).  Without such rows the gain
     // is smaller (melbourne 38.8 -> 37.3) and the plan stays one chain, whose launches are the ones the roofline figures describe.
-    s->two_streams = v.RS >= 1024 && v.n_trow > 0;
+    s->two_streams = v.RS >= 1024;
     if (const char* f = getenv("PEDN_STREAMS")) s->two_streams = atoi(f) == 2;
+    // Owner-wave plan of pedn_run (launch_step: lazy): node_kernel<LU>(t + 1) performs the link update of t, one launch per step.  The
+    // default for models whose second launch is the link update alone (no turning fractions computed on the device): melbourne x 1024
+    // 37.4 -> 32.7-33.7 us per step on one chain, 34.6 -> 30.3 on two (profiles/r04_owner_wave.txt).  With dynamic rows the second launch
+    // stays (node_kernel(t + 1) needs the fractions that need node_kernel(t)'s flows) and the longer node_kernel costs more than the
+    // link-update workgroups that leave it save (delft x 1024: 42.1-42.6 -> 44.2).  PEDN_LINK_OWNER=0|1 overrides.
+    s->link_owner = v.n_trow == 0 && m->node_model != PEDN_NODE_OPTIMAL;
+    if (const char* f = getenv("PEDN_LINK_OWNER")) s->link_owner = atoi(f) != 0;
     s->node_lp = m->node_model == PEDN_NODE_OPTIMAL;
     if (s->node_lp) {  // tableau workspace: one per (regular node, replica group), sized for the largest such node
       int n_lp = 0, max_m = 0;
@@ -769,6 +821,7 @@ int pedn_reset(pedn_sim* s) {
   HIP_TRY(s, hipSetDevice(s->device));
   s->tp_ready = -1;
   s->last_t = -1;
+  s->link_pending = -1;
   return reset_state(s);
 }
 
@@ -994,32 +1047,82 @@ int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
 }
 
 typedef void (*node_kernel_fn)(DevView, int);
-static node_kernel_fn node_kernel_for(const pedn_sim* s) {
+// lu: the instantiation whose slot waves perform the link update of step t-1 themselves (node_kernel<..., LU = true>)
+static node_kernel_fn node_kernel_for(const pedn_sim* s, bool lu = false) {
   const bool h = s->v.hist != 0;  // recent-history mode: the instantiations that mask the history rows
   const bool d6 = s->max_degree <= 6;  // loops and the row of turning fractions unrolled for 6 instead of 8 corridors per node
-#define PEDN_NK(PR_, W_, LP_) (h ? (d6 ? node_kernel<PR_, W_, LP_, true, 6> : node_kernel<PR_, W_, LP_, true, 8>) \
-                                 : (d6 ? node_kernel<PR_, W_, LP_, false, 6> : node_kernel<PR_, W_, LP_, false, 8>))
-  if (s->node_lp) return s->v.pr ? PEDN_NK(true, 6, true) : PEDN_NK(false, 6, true);   // at 8 waves the LP instantiations spill 4..14 vector registers
-  if (s->v.pr) return s->node_waves_pr == 8 ? PEDN_NK(true, 8, false) : PEDN_NK(true, 6, false);
-  return s->node_waves == 8 ? PEDN_NK(false, 8, false) : PEDN_NK(false, 6, false);
+#define PEDN_NK(PR_, W_, LP_, LU_) (h ? (d6 ? node_kernel<PR_, W_, LP_, true, 6, LU_> : node_kernel<PR_, W_, LP_, true, 8, LU_>) \
+                                      : (d6 ? node_kernel<PR_, W_, LP_, false, 6, LU_> : node_kernel<PR_, W_, LP_, false, 8, LU_>))
+  if (s->node_lp) return s->v.pr ? PEDN_NK(true, 6, true, false) : PEDN_NK(false, 6, true, false);   // at 8 waves the LP instantiations spill 4..14 vector registers
+  if (lu) {
+    if (s->v.pr) return s->lu_waves_pr == 8 ? PEDN_NK(true, 8, false, true) : PEDN_NK(true, 6, false, true);
+    return s->lu_waves == 8 ? PEDN_NK(false, 8, false, true) : PEDN_NK(false, 6, false, true);
+  }
+  if (s->v.pr) return s->node_waves_pr == 8 ? PEDN_NK(true, 8, false, false) : PEDN_NK(true, 6, false, false);
+  return s->node_waves == 8 ? PEDN_NK(false, 8, false, false) : PEDN_NK(false, 6, false, false);
 #undef PEDN_NK
+}
+
+// The link update of step t as a launch of its own (the second launch of a step of a model without dynamic turning fractions, and
+// the flush of a pending update under the owner-wave plan).  e >= 0: start / stop events ev[e], ev[e + 1].
+static unsigned link_blocks(const pedn_sim* s, const DevView& v, bool one_r, int ns) {
+  return v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (one_r ? v.subRS : v.subRS / (2 * ns)) + 255) / 256) : 0u;
+}
+static void launch_link_update(pedn_sim* s, const DevView& v, hipStream_t stream, int t, hipEvent_t* ev, int e) {
+  auto launch = [&](auto kernel, dim3 grid, dim3 block, auto... args) {
+    if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev[e], ev[e + 1], 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
+  };
+  const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0) ? 2 : 1;
+  const bool one_r = v.pr || s->link_ns == 0;   // one replica per lane (link_kernel_1r)
+  const unsigned nlb = link_blocks(s, v, one_r, ns);
+  if (nlb == 0) return;
+  if (v.pr) { if (v.hist) launch(link_kernel_1r<true, true>, dim3(nlb), dim3(256), v, t); else launch(link_kernel_1r<true, false>, dim3(nlb), dim3(256), v, t); }
+  else if (one_r) { if (v.hist) launch(link_kernel_1r<false, true>, dim3(nlb), dim3(256), v, t); else launch(link_kernel_1r<false, false>, dim3(nlb), dim3(256), v, t); }
+  else if (ns == 2) { if (v.hist) launch(link_kernel<2, true>, dim3(nlb), dim3(256), v, t); else launch(link_kernel<2, false>, dim3(nlb), dim3(256), v, t); }
+  else { if (v.hist) launch(link_kernel<1, true>, dim3(nlb), dim3(256), v, t); else launch(link_kernel<1, false>, dim3(nlb), dim3(256), v, t); }
+}
+
+// this launch's share of the batch: the whole of it on the engine's stream (half = -1) or one half of the replicas per stream
+static DevView view_of(const pedn_sim* s, int half, hipStream_t* stream) {
+  DevView v = s->v;
+  *stream = s->stream;
+  if (half >= 0) {
+    v.subRS = s->v.RS / 2;
+    v.sub0 = half * v.subRS;
+    if (half == 1) *stream = s->stream2;
+  }
+  return v;
+}
+
+// Owner-wave plan: the link update of the last step launched is still to be done (link_pending); do it now.
+static void flush_links(pedn_sim* s, int half = -1, hipEvent_t* ev = nullptr) {
+  if (s->link_pending < 0) return;
+  hipStream_t stream;
+  const DevView v = view_of(s, half, &stream);
+  launch_link_update(s, v, stream, s->link_pending, ev, 4);
+  if (half != 0) s->link_pending = -1;
 }
 
 // One step = node_kernel(t), then ONE launch with the link update of t and -- where they apply -- the turn probabilities of
 // t+1 (models with softmax groups) and the RL observations / rewards of t (observe >= 0: the accumulate flag of
 // rl_observe; only pedn_rl_step asks for it).  ev != nullptr: per-launch start/stop events {turn_prob, node, link} for
 // pedn_profile_step.  Returns 1 through *observed when the observations were part of the launch.
+// lazy (owner-wave plan, pedn_run): the link update of t is left to node_kernel<LU>(t + 1) -- or to flush_links -- and this step's
+// node_kernel performs the pending one of t - 1.
 static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe = -1, bool* observed = nullptr,
-                       const double* fold_actions = nullptr, int half = -1) {
+                       const double* fold_actions = nullptr, int half = -1, bool lazy = false) {
   // half = -1: the whole batch on the engine's stream; 0 / 1: the first / second half of the replicas on stream / stream2 (the
   // caller, pedn_run, launches both halves of a step and does the per-step bookkeeping once, after the second one)
-  DevView v = s->v;
-  hipStream_t stream = s->stream;
-  if (half >= 0) {
-    v.subRS = s->v.RS / 2;
-    v.sub0 = half * v.subRS;
-    if (half == 1) stream = s->stream2;
-  }
+  hipStream_t stream;
+  DevView v = view_of(s, half, &stream);
+  lazy = lazy && !s->node_lp && v.n_pairs_corr > 0;
+  // a pending link update is flushed when this is not the step it waits for, or when this step starts with the stand-alone turning
+  // fractions (they read num_pedestrians[t - 1] as stored)
+  const bool tf_alone = v.n_trow > 0 && s->tp_ready != t;
+  const bool flush_now = s->link_pending >= 0 && (!(lazy && s->link_pending == t - 1) || tf_alone);
+  const bool lu = lazy && s->link_pending == t - 1 && t >= 2 && !flush_now;   // (half 0 of a pair leaves link_pending as it is)
+  if (flush_now) flush_links(s, half);
   DevView vn = v;                 // node_kernel's view: with the action rows when it applies the gater actions itself
   vn.rl_actions = fold_actions;
   const unsigned rgroups = (unsigned)(v.subRS / 64);
@@ -1031,18 +1134,19 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev[e], ev[e + 1], 0, args...);
     else hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
   };
-  if (groups && s->tp_ready != t) {  // first step of an episode, a repeated or an out-of-order step
+  if (tf_alone) {  // first step of an episode, a repeated or an out-of-order step
     const unsigned nb = (unsigned)((v.n_trow + 3) / 4) * rgroups;  // one wave per (row of a dynamic node, 64 replicas)
     if (v.pr) { if (v.hist) launch(turn_frac_kernel<true, true>, dim3(nb), dim3(256), 0, v, t); else launch(turn_frac_kernel<true, false>, dim3(nb), dim3(256), 0, v, t); }
     else { if (v.hist) launch(turn_frac_kernel<false, true>, dim3(nb), dim3(256), 0, v, t); else launch(turn_frac_kernel<false, false>, dim3(nb), dim3(256), 0, v, t); }
     s->tp_ran = 1;
   }
-  if (ev) hipExtLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, ev[2], ev[3], 0, vn, t);
-  else hipLaunchKernelGGL(node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, vn, t);
+  if (ev) hipExtLaunchKernelGGL(node_kernel_for(s, lu), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, ev[2], ev[3], 0, vn, t);
+  else hipLaunchKernelGGL(node_kernel_for(s, lu), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, vn, t);
   // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
   const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0 && !obs_fused) ? 2 : 1;   // (the diagnostic NS = 2 has no OBS instantiation)
   const bool one_r = v.pr || (s->link_ns == 0 && !fused && !obs_fused);   // one replica per lane (link_kernel_1r)
-  const unsigned nlb = v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (one_r ? v.subRS : v.subRS / (2 * ns)) + 255) / 256) : 0u;
+  const unsigned nlb = lazy ? 0u : link_blocks(s, v, one_r, ns);   // lazy: no link-update workgroups in this step's second launch
+  if (half != 0) s->link_pending = lazy ? t : -1;
   s->second_launch = 1;
   if (fused || obs_fused) {
     const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;
@@ -1066,10 +1170,7 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
 #undef PEDN_LT
     if (fused && half != 0) s->tp_ready = t + 1;   // half 0: the second half of this step still has to see the old value
   } else if (nlb > 0) {
-    if (v.pr) { if (v.hist) launch(link_kernel_1r<true, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel_1r<true, false>, dim3(nlb), dim3(256), 4, v, t); }
-    else if (one_r) { if (v.hist) launch(link_kernel_1r<false, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel_1r<false, false>, dim3(nlb), dim3(256), 4, v, t); }
-    else if (ns == 2) { if (v.hist) launch(link_kernel<2, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel<2, false>, dim3(nlb), dim3(256), 4, v, t); }
-    else { if (v.hist) launch(link_kernel<1, true>, dim3(nlb), dim3(256), 4, v, t); else launch(link_kernel<1, false>, dim3(nlb), dim3(256), 4, v, t); }
+    launch_link_update(s, v, stream, t, ev, 4);
   }
   else s->second_launch = 0;
   if (observed) *observed = obs_fused;
@@ -1135,19 +1236,34 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
   // half is in its link update (few, long waves) the other half's node_kernel fills the machine, and the ramp and the tail of
   // every launch overlap the other chain's work.  Forking and joining costs two cross-stream waits per CALL, so only ranges of
   // several steps take this plan; everything else (single steps, RL steps, profiling) stays on the one stream.
+  // Owner-wave plan (link_owner): one launch per step for models without dynamic turning fractions -- node_kernel<LU>(t) performs the
+  // link update of t - 1 -- plus one link_kernel for the last step of the range.
+  const bool lazy = s->link_owner != 0 && t1 - t0 >= 2;
   if (two_chains(s, t0, t1)) {
     HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
     HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
     for (int t = t0; t < t1; ++t) {
-      launch_step(s, t, nullptr, -1, nullptr, nullptr, 0);
-      launch_step(s, t, nullptr, -1, nullptr, nullptr, 1);
+      launch_step(s, t, nullptr, -1, nullptr, nullptr, 0, lazy);
+      launch_step(s, t, nullptr, -1, nullptr, nullptr, 1, lazy);
     }
+    flush_links(s, 0);
+    flush_links(s, 1);
     const int rc = join_chains(s);
     if (rc != PEDN_OK) return rc;
   } else {
-    for (int t = t0; t < t1; ++t) launch_step(s, t);
+    for (int t = t0; t < t1; ++t) launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, lazy);
+    flush_links(s);
   }
   HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
+int pedn_plan_info(pedn_sim* s, int32_t* info, int32_t n) {
+  if (!s || !info || n < 4) return fail(s, PEDN_E_ARG, "pedn_plan_info: null argument or fewer than 4 entries");
+  info[0] = s->two_streams ? 2 : 1;
+  info[1] = s->link_owner && !s->node_lp && s->v.n_pairs_corr > 0;
+  info[2] = s->stream_probe_attempts;
+  info[3] = (int32_t)(s->stream_probe_ms * 1000.0f + 0.5f);
   return PEDN_OK;
 }
 
@@ -1170,11 +1286,12 @@ struct ProfRow { int t, chain, kind; float start, end; };
 static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows, int* chains) {
   const bool two = two_chains(s, t0, t1);
   const int halves = two ? 2 : 1, n = (t1 - t0) * halves;
+  const bool lazy = s->link_owner != 0 && t1 - t0 >= 2;   // pedn_run's plan
   struct Events {  // destroyed on every way out of the function
     std::vector<hipEvent_t> e;
     ~Events() { for (hipEvent_t x : e) if (x) hipEventDestroy(x); }
   } evs;
-  evs.e.assign((size_t)n * 6, nullptr);
+  evs.e.assign((size_t)(n + halves) * 6, nullptr);   // the last `halves` sets: the trailing link update of the owner-wave plan
   std::vector<hipEvent_t>& ev = evs.e;
   for (auto& e : ev) HIP_TRY(s, hipEventCreate(&e));
   std::vector<int> tp_ran((size_t)n, 0), second((size_t)n, 0);
@@ -1185,10 +1302,12 @@ static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows
   for (int t = t0, k = 0; t < t1; ++t)
     for (int h = 0; h < halves; ++h, ++k) {
       s->tp_ran = 0;
-      launch_step(s, t, &ev[(size_t)k * 6], -1, nullptr, nullptr, two ? h : -1);
+      launch_step(s, t, &ev[(size_t)k * 6], -1, nullptr, nullptr, two ? h : -1, lazy);
       tp_ran[k] = s->tp_ran;
       second[k] = s->second_launch;
     }
+  const bool flushed = s->link_pending >= 0;
+  for (int h = 0; h < halves; ++h) flush_links(s, two ? h : -1, &ev[(size_t)(n + h) * 6]);
   if (two) {
     const int rc = join_chains(s);
     if (rc != PEDN_OK) return rc;
@@ -1207,6 +1326,12 @@ static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows
       HIP_TRY(s, hipEventElapsedTime(&r.end, origin, ev[(size_t)k * 6 + 2 * kind + 1]));
       rows.push_back(r);
     }
+  }
+  for (int h = 0; h < halves && flushed; ++h) {   // the trailing link update: the second launch of the range's last step
+    ProfRow r{t1 - 1, h, 2, 0.0f, 0.0f};
+    HIP_TRY(s, hipEventElapsedTime(&r.start, origin, ev[(size_t)(n + h) * 6 + 4]));
+    HIP_TRY(s, hipEventElapsedTime(&r.end, origin, ev[(size_t)(n + h) * 6 + 5]));
+    rows.push_back(r);
   }
   *chains = halves;
   return PEDN_OK;

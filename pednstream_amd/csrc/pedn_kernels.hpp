@@ -198,6 +198,56 @@ __device__ double recv_flow(const DevView& v, const LinkP& P, int l, int tp, int
   return rr > 0.0 ? rr : 0.0;
 }
 
+// BiDirectionalFd.__call__ + the travel-time part of Link.update_speeds for one direction and one replica; pure arithmetic
+struct SpeedOut { float spd, tt, lf, att, rs; };
+
+// the speed noise of (link, step, replica) (functions.py:132-133): depends on no simulation state, so callers draw it while
+// their loads are in flight
+__device__ __forceinline__ double speed_noise(const DevView& v, const LinkP& P, int l, int t, int r) {
+  if (!(P.noise > 0.0) || v.meanfield) return 0.0;
+  RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)t, 3u};
+  return P.noise * rng_z(key);
+}
+
+__device__ __forceinline__ SpeedOut speed_calc(const DevView& v, const LinkP& P, int l, int t, int r, float ks, float ko,
+                                               float rsum_prev, float tt_old, double nz) {
+  float ke = P.sep ? ks : ks + (float)P.bi * ko;  // functions.py:113
+  bool is64;  // true: the speed is a Python float (binary64) at this point, false: np.float32
+  double v64 = 0.0;
+  float v32 = 0.0f;
+  if (P.fd == 2 && ke <= (float)P.kc) {
+    v32 = (float)P.vf * (1.0f - ke / (float)P.kj);
+    is64 = false;
+  } else if (ke <= (float)P.kc) {
+    v64 = P.vf;
+    is64 = true;
+  } else {
+    if (P.fd == 0) v32 = (float)((P.kc * P.vf) / (P.kj - P.kc)) * ((float)P.kj / ke - 1.0f);
+    else if (P.fd == 1) v32 = ((float)(-P.vf) * (ke - (float)P.kj)) / (float)(P.kj - P.kc);
+    else v32 = (float)(P.vf * P.kc) * (1.0f / ke - (float)(1 / P.kj));
+    is64 = false;
+    if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }  // Python max(0, x) returns the int 0
+  }
+  if (P.noise > 0.0) {  // functions.py:132-133, nz = speed_noise(...)
+    if (is64) v64 = v64 + nz;
+    else v32 = v32 + (float)nz;
+  }
+  if (is64) { if (!(v64 > 0.0)) v64 = 0.0; }
+  else if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }
+  SpeedOut o;
+  o.spd = is64 ? (float)v64 : v32;
+  if (is64) o.tt = v64 > 0.0 ? (float)(P.length / v64) : (float)(P.length / 0.05);  // link.py:177
+  else o.tt = (float)P.length / v32;
+  o.lf = ks * o.spd;               // link.py:181
+  o.rs = rsum_prev + o.tt;         // link.py:183-186, float32 running sum
+  o.att = P.tt0;
+  if (t >= v.W) {
+    o.rs = o.rs - tt_old;
+    o.att = o.rs / (float)v.W;
+  }
+  return o;
+}
+
 // ------------------------------------------------------------------------------------------------- kernels
 // wave-uniform values out of a per-lane register: a record is fetched with ONE vector load (lane k holds its k-th word)
 // and its fields are broadcast with v_readlane.  A chain of scalar loads would wait for each record in turn; vector loads
@@ -632,7 +682,15 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // LP: the node model is the linear programme of assign_flows_type 'optimal' instead of the classic proportional rule.
 // MD: degree the row / column loops and the row of turning fractions are unrolled for (the host picks 6 when no node of the
 // model has more incident corridors: 4 vector registers less in a kernel that lives on its last one)
-template <bool PR, int WAVES, bool LP, bool HIST, int MD = PEDN_MAX_DEGREE>
+// LU (link update by the owner wave): every physical link is the incoming link of exactly one slot, and everything the link
+// update of step t-1 needs for that link -- inflow / outflow[t-1] of both directions of the corridor, num_pedestrians[t-2], the
+// running sum, travel_time[t-1-W] -- was written by EARLIER launches.  So the slot wave of node_kernel(t) performs
+// Network.update_link_states(t-1) (network.py:257-264) for its incoming link itself: it derives num_pedestrians[t-1] of both
+// directions and avg_travel_time[t-1] of the incoming link in registers (the values it would otherwise load), stores the
+// incoming link's rows, and carries on.  The gate record of a link (link.py:188) is written by the wave that holds the link as
+// its OUTGOING link: that wave loads the back gate anyway, and reads it before it applies an RL action to it.  pedn_run then needs
+// ONE launch per step (+ one trailing link_kernel for the last step of the range); see launch_step.
+template <bool PR, int WAVES, bool LP, bool HIST, int MD = PEDN_MAX_DEGREE, bool LU = false>
 __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   // dynamic LDS, sized by the host for the fullest block (pedn_create: node_lds): a block of nodes of degree 3..4 needs 24 of
   // the 64 tiles a single degree-8 node would
@@ -693,12 +751,29 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       // back to back (a load skipped by a branch costs a wait at the join); the few values of an `early` step are unused
       SlotIn x;
       const int t_sw = tp + 1 - Pout.tau_sw > 0 ? tp + 1 - Pout.tau_sw : 0;
-      x.n_in = rowp(v.f32[G_N], R32(G_N, tp), lin, L, RS, r0)[lane];
-      x.n_out = rowp(v.f32[G_N], R32(G_N, tp), lout, L, RS, r0)[lane];
-      // density[t'] of a plain link is num_pedestrians[t'] / float32(length * width) (link.py:136): recomputed from n_in with the
-      // link update's own division instead of being read back; a separator's density depends on its width at that time
-      x.k_in = Pin.sep ? rowp(v.f32[G_K], R32(G_K, tp), lin, L, RS, r0)[lane] : 0.0f;
-      x.att_in = rowp(v.f32[G_ATT], R32(G_ATT, tp), lin, L, RS, r0)[lane];
+      double lu_ia = 0.0, lu_oa = 0.0, lu_ib = 0.0, lu_ob = 0.0, lu_npa = 0.0, lu_npb = 0.0;
+      float lu_pa = 0.0f, lu_pb = 0.0f, lu_rs = 0.0f, lu_old = 0.0f;
+      const bool lu_win = tp >= v.W;
+      if (!LU) {
+        x.n_in = rowp(v.f32[G_N], R32(G_N, tp), lin, L, RS, r0)[lane];
+        x.n_out = rowp(v.f32[G_N], R32(G_N, tp), lout, L, RS, r0)[lane];
+        // density[t'] of a plain link is num_pedestrians[t'] / float32(length * width) (link.py:136): recomputed from n_in with the
+        // link update's own division instead of being read back; a separator's density depends on its width at that time
+        x.k_in = Pin.sep ? rowp(v.f32[G_K], R32(G_K, tp), lin, L, RS, r0)[lane] : 0.0f;
+        x.att_in = rowp(v.f32[G_ATT], R32(G_ATT, tp), lin, L, RS, r0)[lane];
+      } else {
+        // inputs of the link update of step t' for the corridor (lin, lout): all of them written by the launches before this one
+        lu_ia = rowp(v.f64[F_IN], R64(F_IN, tp), lin, Lall, RS, r0)[lane];
+        lu_oa = rowp(v.f64[F_OUT], R64(F_OUT, tp), lin, Lall, RS, r0)[lane];
+        lu_ib = rowp(v.f64[F_IN], R64(F_IN, tp), lout, Lall, RS, r0)[lane];
+        lu_ob = rowp(v.f64[F_OUT], R64(F_OUT, tp), lout, Lall, RS, r0)[lane];
+        lu_pa = rowp(v.f32[G_N], R32(G_N, tp - 1), lin, L, RS, r0)[lane];
+        lu_pb = rowp(v.f32[G_N], R32(G_N, tp - 1), lout, L, RS, r0)[lane];
+        lu_rs = v.rsum[(size_t)lin * RS + r];
+        lu_old = lu_win ? rowp(v.f32[G_TT], R32(G_TT, tp - v.W), lin, L, RS, r0)[lane] : 0.0f;
+        if (Pin.sep) lu_npa = v.sepnp[(size_t)lin * RS + r];
+        if (Pout.sep) lu_npb = v.sepnp[(size_t)lout * RS + r];
+      }
       x.co_in = rowp(v.f64[F_CO], R64(F_CO, tp), lin, Lall, RS, r0)[lane];
       x.s_prev = rowp(v.f64[F_S], R64(F_S, tm1), lin, L, RS, r0)[lane];
       x.co_sw = rowp(v.f64[F_CO], R64(F_CO, t_sw), lout, Lall, RS, r0)[lane];
@@ -709,6 +784,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       x.back_out = bu == bu ? bu : v.back[(size_t)lout * RS + r];
       x.sepw_in = Pin.sep ? v.sepw[(size_t)lin * RS + r] : 0.0;
       x.sepw_out = Pout.sep ? v.sepw[(size_t)lout * RS + r] : 0.0;
+      const double lu_gate = x.back_out;
       if (v.rl_actions != nullptr && W.act >= 0 && r < v.R) {
         // ActionApplier for a gater (rl/builders.py:313-352: clip_gater_action_value + back_gate_width setter, link.py:121-126),
         // done by the one wave that consumes the width: back gate of its outgoing link = front gate of its incoming link
@@ -727,7 +803,28 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
         for (int jj = 0; jj < MD - 1; ++jj)
           if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
       }
-      if (!Pin.sep) x.k_in = x.n_in / Pin.area32;
+      if (LU) {
+        // Network.update_link_states(t') for the incoming link (link.py:133-188); the speed noise needs none of the loads
+        const double nz = speed_noise(v, Pin, lin, tp, r);
+        const float na = (float)((double)lu_pa + (lu_ia - lu_oa)), nb = (float)((double)lu_pb + (lu_ib - lu_ob));  // link.py:133-135
+        const double wa = Pin.sep ? x.sepw_in : Pin.width, wb = Pout.sep ? x.sepw_out : Pout.width;
+        // a separator width held as np.float64 turns the division into binary64 (PEDN_W_SEP_NUMPY), see link_update_one
+        const float ka = (Pin.sep && lu_npa != 0.0) ? (float)((double)na / (Pin.length * wa)) : na / (float)(Pin.length * wa);
+        const float kb = (Pout.sep && lu_npb != 0.0) ? (float)((double)nb / (Pout.length * wb)) : nb / (float)(Pout.length * wb);
+        const SpeedOut so = speed_calc(v, Pin, lin, tp, r, ka, kb, lu_rs, lu_old, nz);
+        rowp(v.f32[G_N], R32(G_N, tp), lin, L, RS, r0)[lane] = na;
+        rowp(v.f32[G_K], R32(G_K, tp), lin, L, RS, r0)[lane] = ka;
+        rowp(v.f32[G_V], R32(G_V, tp), lin, L, RS, r0)[lane] = so.spd;
+        rowp(v.f32[G_TT], R32(G_TT, tp), lin, L, RS, r0)[lane] = so.tt;
+        rowp(v.f32[G_LF], R32(G_LF, tp), lin, L, RS, r0)[lane] = so.lf;
+        if (lu_win) rowp(v.f32[G_ATT], R32(G_ATT, tp), lin, L, RS, r0)[lane] = so.att;
+        v.rsum[(size_t)lin * RS + r] = so.rs;
+        // recorded width of the OUTGOING link (link.py:188 / :451-452): its back gate as loaded above, before any action of this step
+        const double go = Pout.sep ? x.sepw_out : lu_gate;
+        if (go != Pout.width || v.hist) rowp(v.f64[F_GATE], R64(F_GATE, tp), lout, L, RS, r0)[lane] = go;
+        x.n_in = na; x.n_out = nb; x.k_in = ka; x.att_in = so.att;
+      }
+      if (!LU && !Pin.sep) x.k_in = x.n_in / Pin.area32;
       co_prev = x.co_in;   // cumulative_outflow[t-1] of the incoming link, reused by update_links below
       ci_prev = x.ci_out;  // cumulative_inflow[t-1] of the outgoing link
       PH(2, x.n_in + x.k_in + x.att_in + (float)(x.co_in + x.s_prev + x.co_sw + x.ci_out + x.r_prev + x.front_in + x.back_out));
@@ -839,56 +936,6 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     g_phase[w * 12 + 11] += ph[9] - ph[0];
   }
 #endif
-}
-
-// BiDirectionalFd.__call__ + the travel-time part of Link.update_speeds for one direction and one replica; pure arithmetic
-struct SpeedOut { float spd, tt, lf, att, rs; };
-
-// the speed noise of (link, step, replica) (functions.py:132-133): depends on no simulation state, so callers draw it while
-// their loads are in flight
-__device__ __forceinline__ double speed_noise(const DevView& v, const LinkP& P, int l, int t, int r) {
-  if (!(P.noise > 0.0) || v.meanfield) return 0.0;
-  RngKey key{v.k0, v.k1, v.replica_offset + (uint32_t)r, (uint32_t)l, (uint32_t)t, 3u};
-  return P.noise * rng_z(key);
-}
-
-__device__ __forceinline__ SpeedOut speed_calc(const DevView& v, const LinkP& P, int l, int t, int r, float ks, float ko,
-                                               float rsum_prev, float tt_old, double nz) {
-  float ke = P.sep ? ks : ks + (float)P.bi * ko;  // functions.py:113
-  bool is64;  // true: the speed is a Python float (binary64) at this point, false: np.float32
-  double v64 = 0.0;
-  float v32 = 0.0f;
-  if (P.fd == 2 && ke <= (float)P.kc) {
-    v32 = (float)P.vf * (1.0f - ke / (float)P.kj);
-    is64 = false;
-  } else if (ke <= (float)P.kc) {
-    v64 = P.vf;
-    is64 = true;
-  } else {
-    if (P.fd == 0) v32 = (float)((P.kc * P.vf) / (P.kj - P.kc)) * ((float)P.kj / ke - 1.0f);
-    else if (P.fd == 1) v32 = ((float)(-P.vf) * (ke - (float)P.kj)) / (float)(P.kj - P.kc);
-    else v32 = (float)(P.vf * P.kc) * (1.0f / ke - (float)(1 / P.kj));
-    is64 = false;
-    if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }  // Python max(0, x) returns the int 0
-  }
-  if (P.noise > 0.0) {  // functions.py:132-133, nz = speed_noise(...)
-    if (is64) v64 = v64 + nz;
-    else v32 = v32 + (float)nz;
-  }
-  if (is64) { if (!(v64 > 0.0)) v64 = 0.0; }
-  else if (!(v32 > 0.0f)) { v64 = 0.0; is64 = true; }
-  SpeedOut o;
-  o.spd = is64 ? (float)v64 : v32;
-  if (is64) o.tt = v64 > 0.0 ? (float)(P.length / v64) : (float)(P.length / 0.05);  // link.py:177
-  else o.tt = (float)P.length / v32;
-  o.lf = ks * o.spd;               // link.py:181
-  o.rs = rsum_prev + o.tt;         // link.py:183-186, float32 running sum
-  o.att = P.tt0;
-  if (t >= v.W) {
-    o.rs = o.rs - tt_old;
-    o.att = o.rs / (float)v.W;
-  }
-  return o;
 }
 
 __device__ __forceinline__ double2 ld2(const double* p, size_t i) { return *reinterpret_cast<const double2*>(p + i); }
@@ -1339,6 +1386,11 @@ __global__ void draw_demand_kernel(double* dst, size_t row, int T1, int R, int R
 
 // first work on the engine's second stream (pedn_hip.hip: warm_second_stream)
 __global__ void noop_kernel() {}
+// busy for `ticks` of the constant 100 MHz clock (pedn_hip.hip: probe_overlap); every wave reaches the exit
+__global__ void spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
 
 __global__ void device_math_kernel(int op, int n, const double* a, const double* b, uint32_t k0, uint32_t k1, double* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PEDN_HIP_LIB") or os.path.join(_HERE, "csrc", "libpedn_hip.so")   # env override: A/B builds
 
 PEDN_ALL = -1
-ABI_VERSION = 2
+ABI_VERSION = 3
 ERROR_BITS = {1: "negative sending flow (ValueError, link.py:345-346,365-366)",
               2: "negative flows at a node (Warning, node.py:192-194,218-219,237-238)",
               4: "history index out of range (IndexError)",
@@ -153,6 +153,7 @@ def _load():
         "pedn_profile_run": (C.c_int, [P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
         "pedn_profile_timeline": (C.c_int, [P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "pedn_set_streams": (C.c_int, [P, C.c_int32]),
+        "pedn_plan_info": (C.c_int, [P, _I32P, C.c_int32]),
         "pedn_set_link_params": (C.c_int, [P, _F64P, _F64P, _F64P, _I32P, _I32P, _F32P]),
         "pedn_set_od_weights_per_replica": (C.c_int, [P, _F64P]),
         "pedn_rl_configure": (C.c_int, [P, C.POINTER(RlDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -162,11 +163,14 @@ def _load():
         "pedn_rl_device_ptr": (C.c_void_p, [P, C.c_int32]),
         "pedn_device_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _F64P, _F64P, C.c_uint64, _F64P]),
     }
+    # the version first: a stale or alternate library (PEDN_HIP_LIB) must fail with this message, not with an AttributeError on a symbol
+    lib.pedn_abi_version.restype, lib.pedn_abi_version.argtypes = C.c_int, []
+    if lib.pedn_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH}: ABI version {lib.pedn_abi_version()}, this package needs {ABI_VERSION} -- rebuild with "
+                           f"`make -C pednstream_amd/csrc`")
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.pedn_abi_version() != ABI_VERSION:
-        raise RuntimeError("libpedn_hip.so ABI version mismatch")
     return lib
 
 
@@ -183,7 +187,7 @@ def lib():
 EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand", "pedn_set_demand_matrix", "pedn_set_demand_rows", "pedn_get_demand", "pedn_draw_demand",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
-           "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_rl_configure",
+           "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_plan_info", "pedn_rl_configure",
            "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
            "pedn_set_od_weights_per_replica"]
 
@@ -386,6 +390,13 @@ class Engine:
         n, chains = C.c_int32(0), C.c_int32(0)
         self._ck(self._lib.pedn_profile_timeline(self._h, int(t0), int(t1), buf.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n), C.byref(chains)))
         return buf[:5 * n.value].reshape(-1, 5).astype(np.float64), int(chains.value)
+
+    def plan_info(self):
+        """The launch plan of run(): chains, owner-wave link update, and the result of the stream-overlap probe (include/pedn.h)."""
+        info = np.zeros(4, dtype=np.int32)
+        self._ck(self._lib.pedn_plan_info(self._h, info.ctypes.data_as(_I32P), 4))
+        return {"chains": int(info[0]), "link_update_by_next_node_kernel": bool(info[1]), "stream_probe_attempts": int(info[2]),
+                "stream_probe_us": int(info[3])}
 
     def set_streams(self, n):
         """Launch plan of run() for long ranges: 1 chain of launches, or 2 (the halves of the replica batch on two streams)."""

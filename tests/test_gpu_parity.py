@@ -184,7 +184,9 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
 
-    def history(fuse, waves, stepwise, general="0", lds_limit="64", md="6", link_ns="0", heavy="2", pairs_adj="1"):
+    def history(fuse, waves, stepwise, general="0", lds_limit="64", md="6", link_ns="0", heavy="2", pairs_adj="1", owner="0"):
+        monkeypatch.setenv("PEDN_LINK_OWNER", owner)          # 1: pedn_run's owner-wave plan -- node_kernel<LU>(t + 1) performs the link update of t
+        monkeypatch.setenv("PEDN_LU_WAVES", waves)
         monkeypatch.setenv("PEDN_PAIRS_ADJ", pairs_adj)        # 0: the link update takes its two link ids from the corridor's record (models whose
                                                                # directions are not numbered 2p, 2p + 1), 1: from the corridor index where the model allows
         monkeypatch.setenv("PEDN_TF_HEAVY_GROUPS", heavy)      # which rows of dynamic nodes go in front of the link update inside link_turn_kernel
@@ -205,6 +207,12 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
             net.engine().reset()                                      # second episode on the same engine
             for t in range(1, steps):
                 net.network_loading(t)
+        elif owner == "1":                                            # ranges of one, two and many steps, a single step in between
+            net.run(1, 2)
+            net.run(2, 4)
+            net.network_loading(4)
+            net.run(5, steps - 3)
+            net.run(steps - 3, steps)
         else:
             net.run(1, steps)
         e = net.engine()
@@ -217,7 +225,9 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
                     ("1", "8", True, "0", "0"), ("1", "8", False, "0", "64", "8"), ("1", "6", False, "0", "64", "8"),
                     ("0", "8", False, "0", "64", "6", "1"), ("0", "8", True, "0", "64", "6", "2"), ("1", "8", False, "0", "64", "6", "2"),
                     ("1", "8", False, "0", "64", "6", "0", "0"), ("1", "8", True, "0", "64", "6", "0", "100"),
-                    ("1", "8", False, "0", "64", "6", "0", "2", "0"), ("0", "8", True, "0", "64", "6", "0", "2", "0")):
+                    ("1", "8", False, "0", "64", "6", "0", "2", "0"), ("0", "8", True, "0", "64", "6", "0", "2", "0"),
+                    ("1", "8", False, "0", "64", "6", "0", "2", "1", "1"), ("1", "6", False, "0", "64", "6", "0", "2", "1", "1"),
+                    ("0", "8", False, "0", "64", "8", "0", "2", "0", "1"), ("1", "6", False, "0", "64", "8", "2", "2", "1", "1")):
         got = history(*variant)
         for f in ALL_FIELDS:
             assert np.array_equal(ref[f], got[f]), (variant, f)
@@ -381,7 +391,8 @@ def test_per_replica_widths_and_turning_fractions_via_replica_scope():
 
 @pytest.mark.parametrize("name,steps,hist", [("nine_intersections", 150, "full"), ("delft", 40, "full"), ("long_corridor", 150, "full"),
                                              ("melbourne", 60, "full"), ("nine_intersections", 60, "recent"), ("delft", 40, "recent")])
-def test_two_stream_plan_gives_identical_histories(name, steps, hist, monkeypatch):
+@pytest.mark.parametrize("owner", ["0", "1"])
+def test_two_stream_plan_gives_identical_histories(name, steps, hist, owner, monkeypatch):
     """pedn_run launches the two halves of a large batch as two chains on two streams (replicas are independent; the default
     from 1024 replicas).  Same bits as the one-stream plan in every field and every replica, also when the run is cut into
     several calls, continues after a setter, and after a reset; turning fractions and error flags included."""
@@ -390,6 +401,7 @@ def test_two_stream_plan_gives_identical_histories(name, steps, hist, monkeypatc
 
     def history(streams):
         monkeypatch.setenv("PEDN_STREAMS", streams)
+        monkeypatch.setenv("PEDN_LINK_OWNER", owner if streams == "2" else "0")   # the reference side: one chain, two launches per step
         np.random.seed(7)
         net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=256, rng_seed=11, history=hist)
         e = net.engine()
