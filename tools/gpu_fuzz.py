@@ -21,6 +21,8 @@ per_replica = len(sys.argv) > 3 and sys.argv[3] == "scenarios"
 from pednstream_amd.scenarios import ScenarioBatch, derive_statics_arrays
 ran = skipped = flagged = 0
 for seed in range(lo, hi):
+    if seed > lo and (seed - lo) % 200 == 0:     # heartbeat: a long campaign keeps writing (gpurun kills a run that is silent for 7 minutes)
+        print(f"#   ... seed {seed} of {lo}..{hi}: {ran} replica runs bit-exact so far", flush=True)
     adj, params, origins, dests = random_case(seed)
     if os.environ.get("PEDN_FUZZ_OPTIMAL"):          # the node LP instead of the classic rule (engine and oracle: the same simplex)
         params["assign_flows_type"] = "optimal"
@@ -89,4 +91,4 @@ for seed in range(lo, hi):
         assert np.array_equal(tf, o.tf()), (seed, r)
         ran += 1
     net.close()
-print(f"{'per-replica scenarios, ' if per_replica else ''}fuse_tp={os.environ.get('PEDN_FUSE_TP','auto')} seeds {lo}..{hi}: {ran} replica runs bit-exact, {flagged} stopped at a reference raise site (same flag on both sides), {skipped} networks skipped (KeyError like the reference)")
+print(f"{'per-replica scenarios, ' if per_replica else ''}fuse_tp={os.environ.get('PEDN_FUSE_TP','auto')} link_owner={os.environ.get('PEDN_LINK_OWNER','auto')} lu_waves={os.environ.get('PEDN_LU_WAVES','auto')} seeds {lo}..{hi}: {ran} replica runs bit-exact, {flagged} stopped at a reference raise site (same flag on both sides), {skipped} networks skipped (KeyError like the reference)")

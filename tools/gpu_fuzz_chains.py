@@ -21,6 +21,8 @@ from pednstream_amd.network import LINK_FIELDS  # noqa: E402
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 ran = skipped = 0
 for seed in range(lo, hi):
+    if seed > lo and (seed - lo) % 100 == 0:     # heartbeat (gpurun kills a run that is silent for 7 minutes)
+        print(f"#   ... seed {seed} of {lo}..{hi}", flush=True)
     adj, params, origins, dests = random_case(seed)
     if seed % 7 == 0:
         params["assign_flows_type"] = "optimal"

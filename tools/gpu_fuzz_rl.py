@@ -25,6 +25,8 @@ lo, hi = int(sys.argv[1]), int(sys.argv[2])
 B, steps = 4, 30
 ran = no_agents = skipped = 0
 for seed in range(lo, hi):
+    if seed > lo and (seed - lo) % 100 == 0:     # heartbeat (gpurun kills a run that is silent for 7 minutes)
+        print(f"#   ... seed {seed} of {lo}..{hi}", flush=True)
     adj, params, origins, dests = random_case(seed)
     np.random.seed(seed)
     try:
