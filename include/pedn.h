@@ -184,6 +184,9 @@ int pedn_get_turning_fractions(pedn_sim* sim, int32_t node, int32_t replica, dou
 int pedn_set_width(pedn_sim* sim, int32_t which, int32_t link, int32_t replica, double value);
 /* values[n_links][n_replicas] */
 int pedn_set_widths(pedn_sim* sim, int32_t which, const double* values);
+/* every replica back to the same widths (an episode reset): front[n_links], back[n_links], sep[n_links] broadcast, the
+ * "separator width is an np.float64" marks (PEDN_W_SEP_NUMPY) cleared */
+int pedn_reset_widths(pedn_sim* sim, const double* front, const double* back, const double* sep);
 /* current widths -> values[n_links][n_replicas] (the device may have changed them through pedn_rl_apply_actions) */
 int pedn_get_widths(pedn_sim* sim, int32_t which, double* values);
 
@@ -253,9 +256,23 @@ int pedn_reset(pedn_sim* sim);
  * shock-wave look-back (link.py:380) and travel_time[0] (link.py:83).  kc == NULL returns to the shared parameters. */
 int pedn_set_link_params(pedn_sim* sim, const double* kc, const double* kj, const double* vf, const int32_t* free_flow_tau,
                          const int32_t* tau_sw, const float* tt0);
+/* the per-replica link parameters back to the host, matrices [n_links][n_replicas]; any pointer may be NULL */
+int pedn_get_link_params(pedn_sim* sim, double* kc, double* kj, double* vf, int32_t* free_flow_tau, int32_t* tau_sw, float* tt0);
 /* w[n_od][n_replicas]: time-constant OD weights per replica (the randomiser's np.full(T+1, weight)); NULL returns to the
  * shared, time-varying weights of pedn_set_od_weights */
 int pedn_set_od_weights_per_replica(pedn_sim* sim, const double* w);
+int pedn_get_od_weights_per_replica(pedn_sim* sim, double* w);
+/* A new scenario for EVERY replica drawn on the device, in place -- what NetworkEnvGenerator.randomize_network draws per env
+ * (src/utils/env_loader.py:160-181) without the host: `what` bit 0 link parameters (generate_random_link_params :363-424: exactly
+ * int(corridors * link_fraction) corridors per replica without replacement; with probability 1/2 k_critical and k_jam x U(0.6, 1.2)
+ * with the floors max(0.5, .) / max(2 k_c, .); with probability 1/2 free_flow_speed x U(0.6, 0.9); look-backs and travel_time[0]
+ * re-derived, link.py:58-63,83-86,380), bit 1 OD weights (generate_random_od_flows :224-259: U(1, 10) per OD pair, constant over
+ * the episode), bit 2 origin demand (generate_random_demand_params :183-222 + the series of od_manager.py:92-155 as pedn_draw_demand)
+ * for the n_origins nodes listed.  Philox4x32-10 keyed by (seed, global replica id): a function of the seed, independent of how the
+ * ensemble is sharded; the same distributions as the reference's randomisers, NOT numpy's stream (distribution-tested only).
+ * Asynchronous; call pedn_reset afterwards. */
+int pedn_randomize_scenarios(pedn_sim* sim, uint64_t seed, double link_fraction, int32_t what, const int32_t* origin_nodes,
+                             int32_t n_origins);
 
 /* ---- batched RL environment step around the hot path ------------------------------------------------
  * Replaces, for every replica at once, the per-env Python glue of the reference's PettingZoo wrapper:

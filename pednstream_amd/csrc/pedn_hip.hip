@@ -69,9 +69,15 @@ struct pedn_sim {
   std::vector<int32_t> h_node_slot_ptr;
   std::vector<double> h_ttab, h_ttab_r;         // host copies of turn_tab [T+1][n_turns] / turn_tab_r [n_turns][R] (tabulated rows: final values)
   std::vector<char> h_rl_link;
-  double *d_kc_r = nullptr, *d_kj_r = nullptr, *d_vf_r = nullptr, *d_pair_pod_r = nullptr, *d_turn_tab_r = nullptr;
-  int32_t *d_fft_r = nullptr, *d_tausw_r = nullptr;
-  float* d_tt0_r = nullptr;  // links whose widths the RL action kernel writes per replica: never uniform
+  LinkPR* d_prm = nullptr;           // per-replica link parameters [L][RS] (pedn_set_link_params, pedn_randomize_scenarios)
+  double *d_pair_pod_r = nullptr, *d_turn_tab_r = nullptr;
+  // per-replica OD weights and the tables derived from them on the device (scenario_pod_tables)
+  double *d_od_w_r = nullptr, *d_pod_tot = nullptr;     // [n_od][RS], [n_up][RS]
+  const int32_t *d_up_od_ptr = nullptr, *d_upod_od = nullptr, *d_upod_up = nullptr, *d_pair_upod = nullptr, *d_turn_pair_ptr = nullptr,
+                *d_turn_mode = nullptr, *d_tab_rows = nullptr;
+  int n_tab_rows = 0, n_upod = 0;
+  bool pod_tables_uploaded = false, ttab_r_stale = false;   // h_ttab_r is older than turn_tab_r on the device
+  int* d_max_tau = nullptr;
   int n_pair = 0, n_up = 0, n_over = 0;
   int n_tf_heavy_quads = 0;  // leading workgroups of turn_frac_body with long chains (more than PEDN_TF_HEAVY_GROUPS softmax groups in a row)
   long step_epoch = 1;  // counts launched steps; h_tf_set_epoch[node] == step_epoch: fractions imposed since the last step
@@ -296,9 +302,75 @@ static int push_matrix(pedn_sim* s, T* dst, const T* src, int n_rows) {
   return PEDN_OK;
 }
 
+// per-replica link-parameter records, allocated at the first use; padding lanes hold valid numbers and stay idle
+static int ensure_link_records(pedn_sim* s) {
+  if (s->d_prm) return PEDN_OK;
+  const DevView& v = s->v;
+  const size_t n = (size_t)v.L * v.RS;
+  int rc = dalloc(s, n, &s->d_prm);
+  if (rc != PEDN_OK) return rc;
+  LinkPR fill;
+  fill.kc = 1.0; fill.kj = 2.0; fill.vf = 1.0; fill.tt0 = 1.0f; fill.fft = 32767; fill.tau_sw = 1;
+  std::vector<LinkPR> h(n, fill);
+  HIP_TRY(s, hipMemcpy(s->d_prm, h.data(), n * sizeof(LinkPR), hipMemcpyHostToDevice));
+  return PEDN_OK;
+}
+
+// device copies of the route-choice tables that P(od | up) per replica is derived from, and its buffers
+static int ensure_pod_tables(pedn_sim* s) {
+  if (s->pod_tables_uploaded) return PEDN_OK;
+  DevView& v = s->v;
+  const int np = s->n_pair, nt = s->n_turns;
+  int rc;
+  std::vector<int32_t> upod_up(std::max<size_t>(s->h_upod_od.size(), 1), 0), rows;
+  for (int u = 0; u < s->n_up; ++u)
+    for (int q = s->h_up_od_ptr[u]; q < s->h_up_od_ptr[u + 1]; ++q) upod_up[q] = u;
+  for (int n = 0; n < s->n_nodes; ++n) {   // the rows finish_tabulated_rows visits
+    const int s0 = s->h_node_slot_ptr[n], d = s->h_node_slot_ptr[n + 1] - s0;
+    for (int i = 0; i < d; ++i)
+      if (s->h_slot_dyn[s0 + i] == 2) { rows.push_back(s->node_turn_ptr[n] + i * (d - 1)); rows.push_back(d - 1); }
+  }
+  s->n_tab_rows = (int)rows.size() / 2;
+  s->n_upod = (int)s->h_upod_od.size();
+  if ((rc = upload(s, s->h_up_od_ptr.data(), s->h_up_od_ptr.size(), &s->d_up_od_ptr)) || (rc = upload(s, s->h_upod_od.data(), s->h_upod_od.size(), &s->d_upod_od)) ||
+      (rc = upload(s, upod_up.data(), upod_up.size(), &s->d_upod_up)) || (rc = upload(s, s->h_pair_upod.data(), s->h_pair_upod.size(), &s->d_pair_upod)) ||
+      (rc = upload(s, s->h_turn_pair_ptr.data(), s->h_turn_pair_ptr.size(), &s->d_turn_pair_ptr)) ||
+      (rc = upload(s, s->h_turn_mode.data(), s->h_turn_mode.size(), &s->d_turn_mode)) || (rc = upload(s, rows.data(), rows.size(), &s->d_tab_rows)))
+    return rc;
+  if ((rc = dalloc(s, (size_t)std::max(s->n_od, 1) * v.RS, &s->d_od_w_r)) || (rc = dalloc(s, (size_t)std::max(s->n_up, 1) * v.RS, &s->d_pod_tot)) ||
+      (rc = dalloc(s, (size_t)np * v.RS, &s->d_pair_pod_r)) || (rc = dalloc(s, (size_t)std::max(nt, 1) * v.RS, &s->d_turn_tab_r)))
+    return rc;
+  HIP_TRY(s, hipMemset(s->d_od_w_r, 0, (size_t)std::max(s->n_od, 1) * v.RS * 8));
+  HIP_TRY(s, hipMemset(s->d_pair_pod_r, 0, (size_t)np * v.RS * 8));
+  HIP_TRY(s, hipMemset(s->d_turn_tab_r, 0, (size_t)std::max(nt, 1) * v.RS * 8));
+  s->pod_tables_uploaded = true;
+  return PEDN_OK;
+}
+
+// P(od | up) and the tabulated rows of every replica from d_od_w_r (path_finder.py:599-615, :691-715), on the device
+static int scenario_pod_tables(pedn_sim* s) {
+  DevView& v = s->v;
+  const int np = s->n_pair, nt = s->n_turns, RS = v.RS;
+  auto blocks = [&](size_t rows) { return dim3((unsigned)((rows * (size_t)RS + 255) / 256)); };
+  if (s->n_up > 0)
+    hipLaunchKernelGGL(pod_tot_kernel, blocks(s->n_up), dim3(256), 0, s->stream, (const double*)s->d_od_w_r, s->d_up_od_ptr, s->d_upod_od, s->n_up, RS, s->d_pod_tot);
+  hipLaunchKernelGGL(pod_pair_kernel, blocks(np), dim3(256), 0, s->stream, (const double*)s->d_od_w_r, s->d_up_od_ptr, s->d_upod_od, s->d_upod_up,
+                     s->d_pair_upod, (const double*)s->d_pod_tot, np, RS, s->d_pair_pod_r);
+  if (nt > 0)
+    hipLaunchKernelGGL(pod_turn_kernel, blocks(nt), dim3(256), 0, s->stream, (const double*)s->d_pair_pod_r, s->d_turn_pair_ptr, s->d_turn_mode, nt, RS, s->d_turn_tab_r);
+  if (s->n_tab_rows > 0)
+    hipLaunchKernelGGL(pod_finish_kernel, blocks(s->n_tab_rows), dim3(256), 0, s->stream, s->d_turn_tab_r, s->d_tab_rows, s->n_tab_rows, RS);
+  HIP_TRY(s, hipGetLastError());
+  v.pair_pod_r = s->d_pair_pod_r; v.turn_tab_r = s->d_turn_tab_r;
+  v.pod_pr = 1;
+  s->ttab_r_stale = true;
+  return PEDN_OK;
+}
+
 extern "C" {
 
 static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows, size_t row0, size_t row_stride, int replica);
+static void flush_links(pedn_sim* s, int half, hipEvent_t* ev);
 
 int pedn_abi_version(void) { return PEDN_ABI_VERSION; }
 
@@ -365,7 +437,11 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     if (v.hist) {
       int max_sw = 0;
       for (int l = 0; l < L; ++l) max_sw = std::max(max_sw, m->link_tau_sw[l]);
-      v.m64[F_CO] = ring(max_sw + 2);     // cumulative_outflow[t' + 1 - tau_shockwave] (link.py:380-390) and [t']
+      // cumulative_outflow[t' + 1 - tau_shockwave] (link.py:380-390) and [t'], with room for the per-replica scenarios of the
+      // randomisers: free_flow_speed x U(0.6, 0.9) stretches the shock-wave look-back by up to 1 / 0.6 (env_loader.py:410-412; the
+      // k_critical / k_jam factor cancels in the shock-wave speed unless a floor binds -- then pedn_set_link_params /
+      // pedn_randomize_scenarios refuse the scenario)
+      v.m64[F_CO] = ring((int)((double)max_sw / 0.6) + 3);
       v.m64[F_OUT] = v.m64[F_S] = v.m64[F_R] = v.m64[F_GATE] = ring(4);   // [t], [t-1], [t-2] at most
       v.m32[G_TT] = ring(v.W + 2);        // travel_time[t - W] leaves the moving average (link.py:183-186)
       v.m32[G_ATT] = v.m32[G_N] = v.m32[G_K] = v.m32[G_V] = v.m32[G_LF] = ring(4);
@@ -982,6 +1058,11 @@ int pedn_get_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, doubl
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   const double* src = (s->h_node_dyn[node] && s->last_t >= 0) ? s->v.tfd[s->last_t & 1] : s->v.tf;
   HIP_TRY(s, hipMemcpy2D(tf, 8, src + (size_t)a * s->v.RS + replica, (size_t)s->v.RS * 8, 8, n, hipMemcpyDeviceToHost));
+  if (s->v.pod_pr && s->ttab_r_stale) {  // the per-replica tables were derived on the device: fetch the host copy once
+    s->h_ttab_r.assign((size_t)std::max(s->n_turns, 1) * s->v.R, 0.0);
+    HIP_TRY(s, hipMemcpy2D(s->h_ttab_r.data(), (size_t)s->v.R * 8, s->d_turn_tab_r, (size_t)s->v.RS * 8, (size_t)s->v.R * 8, std::max(s->n_turns, 1), hipMemcpyDeviceToHost));
+    s->ttab_r_stale = false;
+  }
   if (s->h_node_dyn[node] && s->last_t >= 0 && s->h_tf_set_epoch[node] != s->step_epoch) {  // rows tabulated on the host (SlotRec.dyn == 2)
     const int s0 = s->h_node_slot_ptr[node], d = s->h_node_slot_ptr[node + 1] - s0;
     for (int i = 0; i < d; ++i)
@@ -1032,6 +1113,23 @@ int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
     return push_uniform(s);
   }
   return PEDN_OK;
+}
+
+int pedn_reset_widths(pedn_sim* s, const double* front, const double* back, const double* sep) {
+  if (!s || !front || !back || !sep) return fail(s, PEDN_E_ARG, "null argument");
+  DevView& v = s->v;
+  s->tp_ready = -1;
+  if (v.L == 0) return PEDN_OK;
+  HIP_TRY(s, hipSetDevice(s->device));
+  flush_links(s, -1, nullptr);
+  int rc;
+  if ((rc = push_rows(s, v.front, front, v.L, 0, 1, PEDN_ALL)) || (rc = push_rows(s, v.back, back, v.L, 0, 1, PEDN_ALL)) ||
+      (rc = push_rows(s, v.sepw, sep, v.L, 0, 1, PEDN_ALL)))
+    return rc;
+  HIP_TRY(s, hipMemsetAsync(v.sepnp, 0, (size_t)v.L * v.RS * sizeof(double), s->stream));
+  s->h_front_u.assign(front, front + v.L);
+  s->h_back_u.assign(back, back + v.L);
+  return push_uniform(s);
 }
 
 int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
@@ -1096,7 +1194,7 @@ static DevView view_of(const pedn_sim* s, int half, hipStream_t* stream) {
 }
 
 // Owner-wave plan: the link update of the last step launched is still to be done (link_pending); do it now.
-static void flush_links(pedn_sim* s, int half = -1, hipEvent_t* ev = nullptr) {
+static void flush_links(pedn_sim* s, int half, hipEvent_t* ev) {
   if (s->link_pending < 0) return;
   hipStream_t stream;
   const DevView v = view_of(s, half, &stream);
@@ -1122,7 +1220,7 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   const bool tf_alone = v.n_trow > 0 && s->tp_ready != t;
   const bool flush_now = s->link_pending >= 0 && (!(lazy && s->link_pending == t - 1) || tf_alone);
   const bool lu = lazy && s->link_pending == t - 1 && t >= 2 && !flush_now;   // (half 0 of a pair leaves link_pending as it is)
-  if (flush_now) flush_links(s, half);
+  if (flush_now) flush_links(s, half, nullptr);
   DevView vn = v;                 // node_kernel's view: with the action rows when it applies the gater actions itself
   vn.rl_actions = fold_actions;
   const unsigned rgroups = (unsigned)(v.subRS / 64);
@@ -1246,13 +1344,13 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
       launch_step(s, t, nullptr, -1, nullptr, nullptr, 0, lazy);
       launch_step(s, t, nullptr, -1, nullptr, nullptr, 1, lazy);
     }
-    flush_links(s, 0);
-    flush_links(s, 1);
+    flush_links(s, 0, nullptr);
+    flush_links(s, 1, nullptr);
     const int rc = join_chains(s);
     if (rc != PEDN_OK) return rc;
   } else {
     for (int t = t0; t < t1; ++t) launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, lazy);
-    flush_links(s);
+    flush_links(s, -1, nullptr);
   }
   HIP_TRY(s, hipGetLastError());
   return PEDN_OK;
@@ -1475,28 +1573,54 @@ int pedn_set_link_params(pedn_sim* s, const double* kc, const double* kj, const 
     if (fft[i] < 0 || tau_sw[i] < 0) return fail(s, PEDN_E_ARG, "negative look-back");
     if (v.hist && tau_sw[i] + 2 > s->rows64[F_CO]) return fail(s, PEDN_E_ARG, "shock-wave look-back longer than the cumulative_outflow ring (recent-history mode)");
   }
+  for (size_t i = 0; i < (size_t)v.L * v.R; ++i)
+    if (fft[i] > 32767 || tau_sw[i] > 32767) return fail(s, PEDN_E_ARG, "look-back beyond 32767 steps");
   int rc;
-  const size_t n = (size_t)v.L * v.RS;
-  if (!s->d_kc_r) {
-    if ((rc = dalloc(s, n, &s->d_kc_r)) || (rc = dalloc(s, n, &s->d_kj_r)) || (rc = dalloc(s, n, &s->d_vf_r)) ||
-        (rc = dalloc(s, n, &s->d_fft_r)) || (rc = dalloc(s, n, &s->d_tausw_r)) || (rc = dalloc(s, n, &s->d_tt0_r))) return rc;
-    // padding lanes (replica >= R) must hold valid numbers too: start from a safe fill
-    std::vector<double> one(n, 1.0), two(n, 2.0);
-    HIP_TRY(s, hipMemcpy(s->d_kc_r, one.data(), n * 8, hipMemcpyHostToDevice));
-    HIP_TRY(s, hipMemcpy(s->d_kj_r, two.data(), n * 8, hipMemcpyHostToDevice));
-    HIP_TRY(s, hipMemcpy(s->d_vf_r, one.data(), n * 8, hipMemcpyHostToDevice));
-    std::vector<int32_t> big(n, 1 << 20);  // free_flow_tau far in the future: padding lanes stay idle
-    HIP_TRY(s, hipMemcpy(s->d_fft_r, big.data(), n * 4, hipMemcpyHostToDevice));
-    std::vector<int32_t> onei(n, 1);
-    HIP_TRY(s, hipMemcpy(s->d_tausw_r, onei.data(), n * 4, hipMemcpyHostToDevice));
-    std::vector<float> onef(n, 1.0f);
-    HIP_TRY(s, hipMemcpy(s->d_tt0_r, onef.data(), n * 4, hipMemcpyHostToDevice));
-  }
-  if ((rc = push_matrix(s, s->d_kc_r, kc, v.L)) || (rc = push_matrix(s, s->d_kj_r, kj, v.L)) || (rc = push_matrix(s, s->d_vf_r, vf, v.L)) ||
-      (rc = push_matrix(s, s->d_fft_r, fft, v.L)) || (rc = push_matrix(s, s->d_tausw_r, tau_sw, v.L)) || (rc = push_matrix(s, s->d_tt0_r, tt0, v.L)))
-    return rc;
-  v.kc_r = s->d_kc_r; v.kj_r = s->d_kj_r; v.vf_r = s->d_vf_r; v.fft_r = s->d_fft_r; v.tausw_r = s->d_tausw_r; v.tt0_r = s->d_tt0_r;
+  if ((rc = ensure_link_records(s)) != PEDN_OK) return rc;
+  // the six matrices through one staging slot, packed into the 32-byte records on the device
+  const size_t n = (size_t)v.L * v.R, bytes = n * (3 * 8 + 2 * 4 + 4);
+  pedn_sim::Stage* st;
+  if ((rc = stage_acquire(s, bytes, &st)) != PEDN_OK) return rc;
+  unsigned char* h = (unsigned char*)st->pin;
+  memcpy(h, kc, n * 8); memcpy(h + n * 8, kj, n * 8); memcpy(h + 2 * n * 8, vf, n * 8);
+  memcpy(h + 3 * n * 8, fft, n * 4); memcpy(h + 3 * n * 8 + n * 4, tau_sw, n * 4); memcpy(h + 3 * n * 8 + 2 * n * 4, tt0, n * 4);
+  HIP_TRY(s, hipMemcpyAsync(st->dev, st->pin, bytes, hipMemcpyHostToDevice, s->stream));
+  const unsigned char* d = (const unsigned char*)st->dev;
+  const size_t lanes = (size_t)v.L * v.RS;
+  hipLaunchKernelGGL(pack_link_params_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s->stream, s->d_prm, (const double*)d,
+                     (const double*)(d + n * 8), (const double*)(d + 2 * n * 8), (const int32_t*)(d + 3 * n * 8),
+                     (const int32_t*)(d + 3 * n * 8 + n * 4), (const float*)(d + 3 * n * 8 + 2 * n * 4), v.L, v.R, v.RS);
+  HIP_TRY(s, hipGetLastError());
+  if ((rc = stage_commit(s, st)) != PEDN_OK) return rc;
+  v.prm = s->d_prm;
   v.pr = 1;
+  return PEDN_OK;
+}
+
+int pedn_get_link_params(pedn_sim* s, double* kc, double* kj, double* vf, int32_t* fft, int32_t* tau_sw, float* tt0) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (!s->v.pr || !s->d_prm) return fail(s, PEDN_E_ARG, "no per-replica link parameters are set");
+  HIP_TRY(s, hipSetDevice(s->device));
+  const DevView& v = s->v;
+  const size_t n = (size_t)v.L * v.R, bytes = n * (3 * 8 + 2 * 4 + 4);
+  pedn_sim::Stage* st;
+  int rc = stage_acquire(s, bytes, &st);
+  if (rc != PEDN_OK) return rc;
+  unsigned char* d = (unsigned char*)st->dev;
+  hipLaunchKernelGGL(unpack_link_params_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, (const LinkPR*)s->d_prm,
+                     (double*)d, (double*)(d + n * 8), (double*)(d + 2 * n * 8), (int32_t*)(d + 3 * n * 8), (int32_t*)(d + 3 * n * 8 + n * 4),
+                     (float*)(d + 3 * n * 8 + 2 * n * 4), v.L, v.R, v.RS);
+  HIP_TRY(s, hipGetLastError());
+  HIP_TRY(s, hipMemcpyAsync(st->pin, st->dev, bytes, hipMemcpyDeviceToHost, s->stream));
+  if ((rc = stage_commit(s, st)) != PEDN_OK) return rc;
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  const unsigned char* h = (const unsigned char*)st->pin;
+  if (kc) memcpy(kc, h, n * 8);
+  if (kj) memcpy(kj, h + n * 8, n * 8);
+  if (vf) memcpy(vf, h + 2 * n * 8, n * 8);
+  if (fft) memcpy(fft, h + 3 * n * 8, n * 4);
+  if (tau_sw) memcpy(tau_sw, h + 3 * n * 8 + n * 4, n * 4);
+  if (tt0) memcpy(tt0, h + 3 * n * 8 + 2 * n * 4, n * 4);
   return PEDN_OK;
 }
 
@@ -1510,36 +1634,71 @@ int pedn_set_od_weights_per_replica(pedn_sim* s, const double* w) {
     v.pod_pr = 0;
     return PEDN_OK;
   }
-  const int np = s->n_pair, nt = s->n_turns, R = v.R;
-  if (np == 0) return PEDN_OK;
-  // P(od | up) per replica (path_finder.py:599-615), same arithmetic as tabulate_pair_pod, one column per replica
-  std::vector<double> pod((size_t)np * R), tab((size_t)std::max(nt, 1) * R, 0.0), upod(s->h_upod_od.size());
-  for (int r = 0; r < R; ++r) {
-    for (int u = 0; u < s->n_up; ++u) {
-      const int a = s->h_up_od_ptr[u], b = s->h_up_od_ptr[u + 1];
-      double tot = 0.0;
-      for (int q = a; q < b; ++q) tot += w[(size_t)s->h_upod_od[q] * R + r];
-      for (int q = a; q < b; ++q) upod[q] = tot > 0.0 ? w[(size_t)s->h_upod_od[q] * R + r] / tot : (b - a > 0 ? 1.0 / (double)(b - a) : 0.0);
-    }
-    for (int q = 0; q < np; ++q) pod[(size_t)q * R + r] = upod[s->h_pair_upod[q]];
-    for (int tn = 0; tn < nt; ++tn) {
-      if (!s->h_turn_mode[tn]) continue;
-      double acc = 0.0;
-      for (int q = s->h_turn_pair_ptr[tn]; q < s->h_turn_pair_ptr[tn + 1]; ++q) acc += 1.0 * pod[(size_t)q * R + r];
-      tab[(size_t)tn * R + r] = acc;
-    }
-    finish_tabulated_rows(s, &tab[r], (size_t)R);
-  }
-  s->h_ttab_r = tab;
+  if (s->n_pair == 0) return PEDN_OK;
   int rc;
-  if (!s->d_pair_pod_r) {
-    if ((rc = dalloc(s, (size_t)np * v.RS, &s->d_pair_pod_r)) || (rc = dalloc(s, (size_t)std::max(nt, 1) * v.RS, &s->d_turn_tab_r))) return rc;
-    HIP_TRY(s, hipMemset(s->d_pair_pod_r, 0, (size_t)np * v.RS * 8));
-    HIP_TRY(s, hipMemset(s->d_turn_tab_r, 0, (size_t)std::max(nt, 1) * v.RS * 8));
+  if ((rc = ensure_pod_tables(s)) != PEDN_OK) return rc;
+  if ((rc = push_matrix(s, s->d_od_w_r, w, s->n_od)) != PEDN_OK) return rc;
+  return scenario_pod_tables(s);
+}
+
+int pedn_get_od_weights_per_replica(pedn_sim* s, double* w) {
+  if (!s || !w) return fail(s, PEDN_E_ARG, "null argument");
+  if (!s->v.pod_pr || !s->d_od_w_r) return fail(s, PEDN_E_ARG, "no per-replica OD weights are set");
+  HIP_TRY(s, hipSetDevice(s->device));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  HIP_TRY(s, hipMemcpy2D(w, (size_t)s->v.R * 8, s->d_od_w_r, (size_t)s->v.RS * 8, (size_t)s->v.R * 8, s->n_od, hipMemcpyDeviceToHost));
+  return PEDN_OK;
+}
+
+int pedn_randomize_scenarios(pedn_sim* s, uint64_t seed, double link_fraction, int32_t what, const int32_t* origin_nodes, int32_t n_origins) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (!(link_fraction >= 0.0 && link_fraction <= 1.0)) return fail(s, PEDN_E_ARG, "link_fraction outside [0, 1]");
+  if ((what & 4) && n_origins > 0 && !origin_nodes) return fail(s, PEDN_E_ARG, "origin nodes missing");
+  HIP_TRY(s, hipSetDevice(s->device));
+  DevView& v = s->v;
+  flush_links(s, -1, nullptr);
+  s->tp_ready = -1;
+  const uint32_t k0 = (uint32_t)(seed & 0xffffffffu), k1 = (uint32_t)(seed >> 32);
+  int rc;
+  if ((what & 1) && v.n_pairs_corr > 0) {
+    const int k = (int)((double)v.n_pairs_corr * link_fraction);   // int(len(valid_links) * 0.2), env_loader.py:393
+    if ((rc = ensure_link_records(s)) != PEDN_OK) return rc;
+    if (!s->d_max_tau && (rc = dalloc(s, 1, &s->d_max_tau)) != PEDN_OK) return rc;
+    HIP_TRY(s, hipMemsetAsync(s->d_max_tau, 0, sizeof(int), s->stream));
+    hipLaunchKernelGGL(rand_links_kernel, dim3((unsigned)((v.RS + 63) / 64)), dim3(64), 0, s->stream, v, s->d_prm, k, k0, k1, s->d_max_tau);
+    HIP_TRY(s, hipGetLastError());
+    v.prm = s->d_prm;
+    v.pr = 1;
+    if (v.hist) {  // recent-history mode: the cumulative_outflow ring must cover the longest shock-wave look-back drawn
+      int mt = 0;
+      HIP_TRY(s, hipMemcpyAsync(&mt, s->d_max_tau, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(s, hipStreamSynchronize(s->stream));
+      if (mt + 2 > s->rows64[F_CO]) return fail(s, PEDN_E_ARG, "a drawn shock-wave look-back (" + std::to_string(mt) + ") is longer than the cumulative_outflow ring (recent-history mode)");
+    }
   }
-  if ((rc = push_matrix(s, s->d_pair_pod_r, pod.data(), np)) || (rc = push_matrix(s, s->d_turn_tab_r, tab.data(), nt))) return rc;
-  v.pair_pod_r = s->d_pair_pod_r; v.turn_tab_r = s->d_turn_tab_r;
-  v.pod_pr = 1;
+  if ((what & 2) && s->n_pair > 0) {
+    if ((rc = ensure_pod_tables(s)) != PEDN_OK) return rc;
+    const size_t lanes = (size_t)s->n_od * v.RS;
+    hipLaunchKernelGGL(rand_od_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s->stream, s->d_od_w_r, s->n_od, v.RS, k0, k1, v.replica_offset);
+    if ((rc = scenario_pod_tables(s)) != PEDN_OK) return rc;
+  }
+  if ((what & 4) && n_origins > 0) {
+    std::vector<int32_t> hn((size_t)2 * n_origins);
+    for (int i = 0; i < n_origins; ++i) {
+      const int node = origin_nodes[i];
+      if (node < 0 || node >= s->n_nodes || s->node_demand_row[node] < 0) return fail(s, PEDN_E_ARG, "origin node without a virtual link");
+      hn[i] = s->node_demand_row[node];
+      hn[n_origins + i] = node;
+    }
+    pedn_sim::Stage* st;
+    if ((rc = stage_acquire(s, hn.size() * 4, &st)) != PEDN_OK) return rc;
+    if ((rc = stage_upload(s, st, hn.data(), hn.size() * 4)) != PEDN_OK) return rc;
+    const size_t lanes = (size_t)v.T1 * v.RS;
+    hipLaunchKernelGGL(rand_demand_kernel, dim3((unsigned)((lanes + 255) / 256), (unsigned)n_origins), dim3(256), 0, s->stream, v.demand,
+                       (const int32_t*)st->dev, (const int32_t*)st->dev + n_origins, v.T1, v.R, v.RS, k0, k1, v.replica_offset);
+    HIP_TRY(s, hipGetLastError());
+    if ((rc = stage_commit(s, st)) != PEDN_OK) return rc;
+  }
   return PEDN_OK;
 }
 

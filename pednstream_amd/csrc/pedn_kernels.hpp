@@ -65,9 +65,13 @@ template <bool PR>
 __device__ __forceinline__ LinkP lane_params(const DevView& v, const LinkP& P, int l, int r) {
   LinkP Q = P;
   if (PR) {
-    const size_t i = (size_t)l * v.RS + r;
-    Q.kc = v.kc_r[i]; Q.kj = v.kj_r[i]; Q.vf = v.vf_r[i];
-    Q.fft = v.fft_r[i]; Q.tau_sw = v.tausw_r[i]; Q.tt0 = v.tt0_r[i];
+    // the record as two 16-byte loads
+    const double2* rec = reinterpret_cast<const double2*>(v.prm + ((size_t)l * v.RS + r));
+    const double2 lo = rec[0], hi = rec[1];
+    Q.kc = lo.x; Q.kj = lo.y; Q.vf = hi.x;
+    const int w0 = __double2loint(hi.y), w1 = __double2hiint(hi.y);
+    Q.tt0 = __int_as_float(w0);
+    Q.fft = (int)(short)(w1 & 0xffff); Q.tau_sw = w1 >> 16;
     Q.derive();
   }
   return Q;
@@ -365,7 +369,7 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
       }
       double c = c_l[i];
       if (!(c >= 0.0)) {  // no receiving flow recorded yet: back_gate_width * v_f * k_c * dt (:575-576)
-        const double vfr = PR ? v.vf_r[(size_t)link * RS + r] : vf, kcr = PR ? v.kc_r[(size_t)link * RS + r] : kc;
+        const double vfr = PR ? v.prm[(size_t)link * RS + r].vf : vf, kcr = PR ? v.prm[(size_t)link * RS + r].kc : kc;
         c = v.back[(size_t)link * RS + r] * vfr * kcr * v.dt;
       }
       kf[e] = k;
@@ -1379,6 +1383,193 @@ __global__ void draw_demand_kernel(double* dst, size_t row, int T1, int R, int R
       }
       val = (double)k;
       if (pat == 2 && t >= spike_start[r] && t < spike_start[r] + spike_len[r]) val += spike_height[r];
+    }
+  }
+  dst[(row * T1 + t) * RS + r] = val;
+}
+
+// ---- per-replica scenarios: packing, and the randomisers of env_loader.py:183-259,363-424 on the device ----------------------
+// (travel_time[0], free_flow_tau, tau_shockwave) of a link from its parameters with the expressions of link.py:58-63,83-86,380 and
+// the roundings of scenarios.py: derive_statics_arrays (np.float32 / unit_time is a float32 division; round = rint, half to even)
+__device__ __forceinline__ LinkPR make_link_pr(double kc, double kj, double vf, double length, double dt) {
+  LinkPR q;
+  q.kc = kc; q.kj = kj; q.vf = vf;
+  const double shockwave_speed = (vf * kc) / (kj - kc);
+  const double a = length / vf, b = length / 0.05;
+  q.tt0 = (float)(a < b ? a : b);
+  const int fft = __float2int_rn(q.tt0 / (float)dt), tsw = (int)rint(length / (shockwave_speed * dt));
+  q.fft = (int16_t)(fft > 32767 ? 32767 : fft);
+  q.tau_sw = (int16_t)(tsw > 32767 ? 32767 : (tsw < 0 ? 0 : tsw));
+  return q;
+}
+
+// pedn_set_link_params: six host matrices [L][R] -> records [L][RS]
+__global__ void pack_link_params_kernel(LinkPR* dst, const double* kc, const double* kj, const double* vf, const int32_t* fft,
+                                        const int32_t* tau_sw, const float* tt0, int L, int R, int RS) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)L * RS) return;
+  const int l = (int)(gid / RS), r = (int)(gid % RS);
+  LinkPR q;
+  if (r < R) {
+    const size_t i = (size_t)l * R + r;
+    q.kc = kc[i]; q.kj = kj[i]; q.vf = vf[i]; q.tt0 = tt0[i]; q.fft = (int16_t)fft[i]; q.tau_sw = (int16_t)tau_sw[i];
+  } else {  // padding lanes hold valid numbers and stay idle: free_flow_tau far in the future
+    q.kc = 1.0; q.kj = 2.0; q.vf = 1.0; q.tt0 = 1.0f; q.fft = 32767; q.tau_sw = 1;
+  }
+  dst[gid] = q;
+}
+// pedn_get_link_params: records -> whichever of the six host-layout matrices [L][R] are asked for
+__global__ void unpack_link_params_kernel(const LinkPR* src, double* kc, double* kj, double* vf, int32_t* fft, int32_t* tau_sw, float* tt0,
+                                          int L, int R, int RS) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)L * R) return;
+  const int l = (int)(gid / R), r = (int)(gid % R);
+  const LinkPR q = src[(size_t)l * RS + r];
+  if (kc) kc[gid] = q.kc;
+  if (kj) kj[gid] = q.kj;
+  if (vf) vf[gid] = q.vf;
+  if (fft) fft[gid] = q.fft;
+  if (tau_sw) tau_sw[gid] = q.tau_sw;
+  if (tt0) tt0[gid] = q.tt0;
+}
+
+__device__ __forceinline__ double u01(uint32_t w) { return (double)w * 0x1p-32; }   // [0, 1)
+
+// generate_random_link_params (env_loader.py:363-424) for every replica: one lane per replica walks the corridors and picks exactly
+// k = int(P * fraction) of them without replacement by selection sampling (corridor p is taken with probability
+// (k - taken) / (P - p): every k-subset is equally likely, like np.random.choice(..., replace=False)); a chosen corridor gets, each
+// with probability 1/2, k_critical / k_jam scaled by U(0.6, 1.2) with the floors max(0.5, .) / max(2 k_c, .), and free_flow_speed
+// scaled by U(0.6, 0.9).  Both links of the corridor are scaled from their OWN base parameters (v.lp).  One Philox call per
+// (corridor, replica), keyed by the global replica id: the scenarios do not depend on how the ensemble is sharded.
+__global__ void rand_links_kernel(DevView v, LinkPR* dst, int k, uint32_t k0, uint32_t k1, int* max_tau_sw) {
+  const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (r >= v.RS) return;
+  const int P = v.n_pairs_corr;
+  int taken = 0, tmax = 0;
+  for (int p = 0; p < P; ++p) {
+    uint32_t c[4] = {(uint32_t)p, 0x61u, 0u, v.replica_offset + (uint32_t)r};
+    philox4x32_10(c, k0, k1);
+    const bool chosen = (uint64_t)c[0] * (uint64_t)(P - p) < ((uint64_t)(k - taken) << 32);
+    taken += chosen ? 1 : 0;
+    const bool dens = chosen && (c[1] & 0xffffu) < 0x8000u, spd = chosen && (c[1] >> 16) < 0x8000u;
+    const double F = 0.6 + (1.2 - 0.6) * u01(c[2]), G = 0.6 + (0.9 - 0.6) * u01(c[3]);
+    const int ab[2] = {v.pairs_adj ? 2 * p : v.corr_rec[p].a, v.pairs_adj ? 2 * p + 1 : v.corr_rec[p].b};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const LinkP& B = v.lp[ab[h]];
+      double kc = B.kc, kj = B.kj, vf = B.vf;
+      if (dens) {
+        kc = fmax(0.5, B.kc * F);
+        kj = fmax(kc * 2.0, B.kj * F);
+      }
+      if (spd) vf = B.vf * G;
+      const LinkPR q = make_link_pr(kc, kj, vf, B.length, v.dt);
+      tmax = max(tmax, (int)q.tau_sw);
+      dst[(size_t)ab[h] * v.RS + r] = q;
+    }
+  }
+  if (max_tau_sw && r < v.R) atomicMax(max_tau_sw, tmax);
+}
+
+// generate_random_od_flows (env_loader.py:224-259): U(1, 10) per (OD pair, replica), constant over the episode
+__global__ void rand_od_kernel(double* od_w_r, int n_od, int RS, uint32_t k0, uint32_t k1, uint32_t replica_offset) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)n_od * RS) return;
+  const int od = (int)(gid / RS), r = (int)(gid % RS);
+  uint32_t c[4] = {(uint32_t)od, 0x63u, 0u, replica_offset + (uint32_t)r};
+  philox4x32_10(c, k0, k1);
+  od_w_r[gid] = 1.0 + (10.0 - 1.0) * u01(c[0]);
+}
+
+// P(od | up) per replica from time-constant OD weights (path_finder.py:599-615), the arithmetic of tabulate_pair_pod column by column:
+//   pod_tot_kernel     tot[u][r] = sum of the upstream's OD weights in table order
+//   pod_pair_kernel    pair_pod_r[q][r] = w / tot (uniform when the sum is 0)
+//   pod_turn_kernel    turn_tab_r[turn][r] = sum of the products of a turn whose probabilities are all the constant 1 (h_turn_mode)
+//   pod_finish_kernel  check_fractions (path_finder.py:691-715) of the rows tabulated this way: finish_tabulated_rows per replica
+__global__ void pod_tot_kernel(const double* od_w_r, const int32_t* up_od_ptr, const int32_t* upod_od, int n_up, int RS, double* tot) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)n_up * RS) return;
+  const int u = (int)(gid / RS), r = (int)(gid % RS);
+  double t = 0.0;
+  for (int q = up_od_ptr[u]; q < up_od_ptr[u + 1]; ++q) t += od_w_r[(size_t)upod_od[q] * RS + r];
+  tot[gid] = t;
+}
+__global__ void pod_pair_kernel(const double* od_w_r, const int32_t* up_od_ptr, const int32_t* upod_od, const int32_t* upod_up,
+                                const int32_t* pair_upod, const double* tot, int n_pair, int RS, double* pair_pod_r) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)n_pair * RS) return;
+  const int q = (int)(gid / RS), r = (int)(gid % RS);
+  const int x = pair_upod[q], u = upod_up[x], n = up_od_ptr[u + 1] - up_od_ptr[u];
+  const double t = tot[(size_t)u * RS + r];
+  pair_pod_r[gid] = t > 0.0 ? od_w_r[(size_t)upod_od[x] * RS + r] / t : (n > 0 ? 1.0 / (double)n : 0.0);
+}
+__global__ void pod_turn_kernel(const double* pair_pod_r, const int32_t* turn_pair_ptr, const int32_t* turn_mode, int n_turns, int RS,
+                                double* turn_tab_r) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)n_turns * RS) return;
+  const int tn = (int)(gid / RS), r = (int)(gid % RS);
+  double acc = 0.0;
+  if (turn_mode[tn])
+    for (int q = turn_pair_ptr[tn]; q < turn_pair_ptr[tn + 1]; ++q) acc += 1.0 * pair_pod_r[(size_t)q * RS + r];
+  turn_tab_r[gid] = acc;
+}
+__global__ void pod_finish_kernel(double* turn_tab_r, const int32_t* tab_rows, int n_rows, int RS) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)n_rows * RS) return;
+  const int i = (int)(gid / RS), r = (int)(gid % RS);
+  const int ta = tab_rows[2 * i], n = tab_rows[2 * i + 1];
+  double rowsum = 0.0;
+  for (int jj = 0; jj < n; ++jj) {
+    const double f = turn_tab_r[(size_t)(ta + jj) * RS + r];
+    rowsum = (jj == 0) ? f : rowsum + f;
+  }
+  if (fabs(rowsum - 1) > 1e-3)
+    for (int jj = 0; jj < n; ++jj) {
+      const double f = turn_tab_r[(size_t)(ta + jj) * RS + r];
+      turn_tab_r[(size_t)(ta + jj) * RS + r] = rowsum > 1e-6 ? f / rowsum : 1.0 / (double)n;
+    }
+}
+
+// generate_random_demand_params (env_loader.py:183-222) + the series of od_manager.py:92-155 for EVERY origin and replica in one
+// launch: blockIdx.y = origin.  Pattern (uniform over gaussian_peaks / constant / sudden_demand), base U(2, 10), peak max(U(10, 30),
+// base + 5), spike length in [10, 20), start in [0, max(1, T - length)), height in [20, 50) are drawn per (origin, replica); the Poisson
+// series as in draw_demand_kernel.
+__global__ void rand_demand_kernel(double* dst, const int32_t* rows, const int32_t* nodes, int T1, int R, int RS, uint32_t k0, uint32_t k1,
+                                   uint32_t replica_offset) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)T1 * RS) return;
+  const int t = (int)(gid / RS), r = (int)(gid % RS), T = T1 - 1;
+  const uint32_t node = (uint32_t)nodes[blockIdx.y];
+  const size_t row = (size_t)rows[blockIdx.y];
+  double val = 0.0;
+  if (r < R) {
+    uint32_t a[4] = {node, 0x51u, 0u, replica_offset + (uint32_t)r}, b[4] = {node, 0x52u, 0u, replica_offset + (uint32_t)r};
+    philox4x32_10(a, k0, k1);
+    philox4x32_10(b, k0, k1);
+    const int pat = (int)(((uint64_t)a[0] * 3u) >> 32);
+    const double base = 2.0 + 8.0 * u01(a[1]);
+    double peak = 10.0 + 20.0 * u01(a[2]);
+    if (peak < base + 5.0) peak = base + 5.0;
+    const int len = 10 + (int)(((uint64_t)a[3] * 10u) >> 32);
+    const int span = T - len > 1 ? T - len : 1;
+    const int start = (int)(((uint64_t)b[0] * (uint64_t)span) >> 32);
+    const double height = (double)(20 + (int)(((uint64_t)b[1] * 30u) >> 32));
+    if (pat == 1) val = base;
+    else if (t < T) {
+      const double w = (double)T / 20.0, x = ((double)t - (double)T / 4.0), y = ((double)t - 3.0 * (double)T / 4.0);
+      const double lam = base + peak * exp(-(x * x) / (2.0 * w * w)) + peak * exp(-(y * y) / (2.0 * w * w));
+      uint32_t c[4] = {(uint32_t)t, node, 0x50u, replica_offset + (uint32_t)r};
+      philox4x32_10(c, k0, k1);
+      const double u = (double)((((uint64_t)c[0] << 32) | c[1]) >> 11) * 0x1p-53;
+      double p = exp(-lam), cdf = p;
+      int k = 0;
+      while (u > cdf && k < 1000) {
+        ++k;
+        p *= lam / (double)k;
+        cdf += p;
+      }
+      val = (double)k;
+      if (pat == 2 && t >= start && t < start + len) val += height;
     }
   }
   dst[(row * T1 + t) * RS + r] = val;

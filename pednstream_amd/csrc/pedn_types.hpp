@@ -24,6 +24,15 @@ struct LinkP {  // static per-link parameters, wave-uniform on the device
   }
 };
 
+// Per-replica scenario parameters of one (link, replica): ONE 32-byte record -- two 16-byte loads per lane -- instead of six arrays
+// (randomised ensembles / RL resets, env_loader.py:363-424).  The look-backs fit 16 bits (pedn_set_link_params checks).
+struct alignas(16) LinkPR {
+  double kc, kj, vf;      // k_critical, k_jam, free_flow_speed
+  float tt0;              // travel_time[0] (link.py:83)
+  int16_t fft, tau_sw;    // free_flow_tau (link.py:86), shock-wave look-back (link.py:380)
+};
+static_assert(sizeof(LinkPR) == 32, "LinkPR must stay two 16-byte loads");
+
 struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything static it needs, fetched by ONE scalar load burst
   // dyn: where the slot's row of turning fractions comes from -- 0 tf / tf_u (default or imposed), 1 tfd[t & 1] (turn_frac_kernel),
   // 2 turn_tab[t] / turn_tab_r (every product constant: replica-independent, tabulated and renormalised on the host)
@@ -70,9 +79,7 @@ struct DevView {
   const double *front_u, *back_u;  // [L]
   const double* tf_u;              // [n_turns]
   // per-replica scenario parameters (randomised ensembles / RL resets, env_loader.py:363-424); used when pr != 0
-  const double *kc_r, *kj_r, *vf_r;   // [L][RS] k_critical, k_jam, free_flow_speed
-  const int32_t *fft_r, *tausw_r;     // [L][RS] free_flow_tau, shock-wave look-back
-  const float* tt0_r;                 // [L][RS] travel_time[0]
+  const LinkPR* prm;                  // [L][RS] k_critical, k_jam, free_flow_speed, free_flow_tau, shock-wave look-back, travel_time[0]
   const double *pair_pod_r, *turn_tab_r;  // [n_pair][RS], [n_turns][RS]: P(od | up) with per-replica, time-constant OD weights
   int32_t pr, pod_pr;
   const double* od_w;

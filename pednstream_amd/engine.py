@@ -138,6 +138,7 @@ def _load():
         "pedn_set_width": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_double]),
         "pedn_set_widths": (C.c_int, [P, C.c_int32, _F64P]),
         "pedn_get_widths": (C.c_int, [P, C.c_int32, _F64P]),
+        "pedn_reset_widths": (C.c_int, [P, _F64P, _F64P, _F64P]),
         "pedn_step": (C.c_int, [P, C.c_int32]),
         "pedn_run": (C.c_int, [P, C.c_int32, C.c_int32]),
         "pedn_synchronize": (C.c_int, [P]),
@@ -156,6 +157,9 @@ def _load():
         "pedn_plan_info": (C.c_int, [P, _I32P, C.c_int32]),
         "pedn_set_link_params": (C.c_int, [P, _F64P, _F64P, _F64P, _I32P, _I32P, _F32P]),
         "pedn_set_od_weights_per_replica": (C.c_int, [P, _F64P]),
+        "pedn_get_od_weights_per_replica": (C.c_int, [P, _F64P]),
+        "pedn_get_link_params": (C.c_int, [P, _F64P, _F64P, _F64P, _I32P, _I32P, _F32P]),
+        "pedn_randomize_scenarios": (C.c_int, [P, C.c_uint64, C.c_double, C.c_int32, _I32P, C.c_int32]),
         "pedn_rl_configure": (C.c_int, [P, C.POINTER(RlDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "pedn_rl_apply_actions": (C.c_int, [P, C.c_void_p, C.c_int32]),
         "pedn_rl_observe": (C.c_int, [P, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -189,7 +193,13 @@ EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
            "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_plan_info", "pedn_rl_configure",
            "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
-           "pedn_set_od_weights_per_replica"]
+           "pedn_set_od_weights_per_replica", "pedn_get_od_weights_per_replica", "pedn_get_link_params", "pedn_randomize_scenarios", "pedn_reset_widths"]
+
+
+def _p(a, dtype=np.float64):
+    """ctypes pointer to a contiguous numpy array of the given element type."""
+    assert a.dtype == dtype and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as({np.float64: _F64P, np.int32: _I32P, np.float32: _F32P}[dtype])
 
 
 class ModelError(RuntimeError):
@@ -306,6 +316,12 @@ class Engine:
         assert v.shape == (self.n_links, self.n_replicas)
         self._ck(self._lib.pedn_set_widths(self._h, int(which), v.ctypes.data_as(_F64P)))
 
+    def reset_widths(self, front, back, sep):
+        """Every replica back to the widths front / back / sep [n_links] (an episode reset), float64-separator marks cleared."""
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (front, back, sep)]
+        assert all(x.shape == (self.n_links,) for x in a)
+        self._ck(self._lib.pedn_reset_widths(self._h, _p(a[0]), _p(a[1]), _p(a[2])))
+
     def set_link_params(self, kc, kj, vf, fft, tau_sw, tt0):
         """Per-replica k_critical / k_jam / free_flow_speed [n_links, n_replicas] + host-derived look-backs; None resets."""
         if kc is None:
@@ -326,6 +342,26 @@ class Engine:
         w = np.ascontiguousarray(w, dtype=np.float64)
         assert w.shape == (int(self.model["n_od"]), self.n_replicas), w.shape
         self._ck(self._lib.pedn_set_od_weights_per_replica(self._h, w.ctypes.data_as(_F64P)))
+
+    def get_link_params(self):
+        """The per-replica link parameters as they are on the device: dict of [n_links, n_replicas] arrays."""
+        L, R = self.n_links, self.n_replicas
+        out = {"kc": np.empty((L, R)), "kj": np.empty((L, R)), "vf": np.empty((L, R)), "fft": np.empty((L, R), dtype=np.int32),
+               "tau_sw": np.empty((L, R), dtype=np.int32), "tt0": np.empty((L, R), dtype=np.float32)}
+        self._ck(self._lib.pedn_get_link_params(self._h, _p(out["kc"]), _p(out["kj"]), _p(out["vf"]), _p(out["fft"], np.int32),
+                                                _p(out["tau_sw"], np.int32), _p(out["tt0"], np.float32)))
+        return out
+
+    def get_od_weights_per_replica(self):
+        w = np.empty((int(self.model["n_od"]), self.n_replicas))
+        self._ck(self._lib.pedn_get_od_weights_per_replica(self._h, _p(w)))
+        return w
+
+    def randomize_scenarios(self, seed, link_fraction=0.2, links=True, od_weights=True, origin_nodes=()):
+        """pedn_randomize_scenarios: every replica's scenario drawn on the device (origin_nodes: model node indices whose demand is drawn)."""
+        nodes = np.ascontiguousarray(origin_nodes, dtype=np.int32)
+        what = (1 if links else 0) | (2 if od_weights else 0) | (4 if len(nodes) else 0)
+        self._ck(self._lib.pedn_randomize_scenarios(self._h, int(seed) & (2 ** 64 - 1), float(link_fraction), what, _p(nodes, np.int32), len(nodes)))
 
     def get_widths(self, which):
         out = np.empty((self.n_links, self.n_replicas), dtype=np.float64)

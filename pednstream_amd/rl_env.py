@@ -193,8 +193,8 @@ class VecPedNetEnv:
 
         ``mode="reference"``: the reference's randomisers, one np.random stream consumed env after env
         (env_loader.py:183-259,363-424: link parameters of 20 % of the corridors, OD weights, demand pattern / lambdas) --
-        host-bound, ~0.25 ms per env.  ``mode="vectorised"``: the same distributions drawn for all envs at once, demand series
-        on the device (``ScenarioBatch.draw_random``); not the reference's random numbers.  Two deliberate differences from
+        host-bound, ~0.25 ms per env.  ``mode="vectorised"``: the same distributions drawn for all envs at once ON THE DEVICE
+        (``ScenarioBatch.draw_random`` -> ``pedn_randomize_scenarios``: nothing is uploaded); not the reference's random numbers.  Two deliberate differences from
         ``randomize_network`` in both modes: every env is perturbed from the BASE configuration (the reference keeps
         perturbing its already perturbed config), and ``generate_random_od_nodes`` is not applied because it changes the
         topology."""
@@ -206,6 +206,8 @@ class VecPedNetEnv:
         batch = ScenarioBatch(self.network, edge_distances=gen.network_data["edge_distances"])
         if mode == "vectorised":
             batch.draw_random(seed)
+        elif mode == "vectorised_host":           # the numpy generator the device kernels are cross-checked against
+            batch.draw_random_host(seed)
         elif mode == "reference":
             if seed is not None:
                 np.random.seed(seed)
@@ -228,8 +230,8 @@ class VecPedNetEnv:
             self.randomize(seed, mode=options.get("mode", "reference"))
         net.reset()
         net._init_dynamic_host_state()
-        for which, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3)):
-            eng.set_widths(code, net._widths[which])
+        init = net._widths          # every env starts from the same widths: broadcast on the device instead of four [L, R] uploads
+        eng.reset_widths(init["front"][:, 0], init["back"][:, 0], init["sep"][:, 0])
         self.sim_step = 1
         obs, _ = eng.rl_observe(self.sim_step, accumulate=False)
         return obs, {}

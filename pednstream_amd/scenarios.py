@@ -74,8 +74,10 @@ class ScenarioBatch:
         base = {"kc": ("k_critical", np.float64), "kj": ("k_jam", np.float64), "vf": ("free_flow_speed", np.float64),
                 "fft": ("free_flow_tau", np.int32), "tau_sw": ("tau_shockwave", np.int32), "tt0": ("travel_time0", np.float32)}
         self._base = {k: np.array([getattr(l, attr) for l in links], dtype=dt) for k, (attr, dt) in base.items()}
-        for k, col in self._base.items():
-            setattr(self, k, np.repeat(col[:, None], R, axis=1))
+        # the matrices [L, R] (attributes kc, kj, vf, fft, tau_sw, tt0, od_w): host arrays -- or, after draw_random, whatever the device
+        # drew, fetched when somebody looks (see _matrix)
+        self._arr = {k: np.repeat(col[:, None], R, axis=1) for k, col in self._base.items()}
+        self._on_device = set()
         # an override of corridor "u_v" only changes the links between u and v (create_network merges link by link,
         # env_loader.py:93-144): everything below works on the touched node pairs instead of the whole link table
         self._pair_links, self._pair_edges = {}, {}
@@ -83,13 +85,24 @@ class ScenarioBatch:
             self._pair_links.setdefault(frozenset((l.start_node.node_id, l.end_node.node_id)), []).append(l)
         for (u, v), d in (edge_distances or {}).items():        # dict order matters inside a pair
             self._pair_edges.setdefault(frozenset((int(u), int(v))), []).append(((u, v), d))
-        self.od_w = None
+        self._arr["od_w"] = None
         if network.od_manager is not None:
             w0 = network.od_manager.as_matrix()
-            self.od_w = np.repeat(w0[:, :1], R, axis=1)
+            self._arr["od_w"] = np.repeat(w0[:, :1], R, axis=1)
             self._od_index = {od: i for i, od in enumerate(network.od_manager.od_flows.keys())}
         self.demand = {}         # (node_id, replica) -> array
         self.link_params_dirty = self.od_dirty = False
+
+    def _matrix(self, name):
+        if name in self._on_device:          # drawn by pedn_randomize_scenarios: the host copy is made on demand
+            eng = self.net._flush()
+            if name == "od_w":
+                self._arr["od_w"] = eng.get_od_weights_per_replica()
+                self._on_device.discard("od_w")
+            else:
+                self._arr.update(eng.get_link_params())
+                self._on_device -= {"kc", "kj", "vf", "fft", "tau_sw", "tt0"}
+        return self._arr[name]
 
     def _link_overrides(self, r, overrides):
         net = self.net
@@ -152,7 +165,29 @@ class ScenarioBatch:
             self.demand[(nid, r)] = np.asarray(arr, dtype=np.float64)
 
     def draw_random(self, seed, link_fraction=0.2):
-        """A new scenario for EVERY replica, drawn for all replicas at once from the distributions of the reference's
+        """A new scenario for EVERY replica drawn ON THE DEVICE, in place (``pedn_randomize_scenarios``): the distributions of the
+        reference's randomisers -- see ``draw_random_host``, the same thing in numpy -- keyed (seed, global replica id) with
+        Philox, so a function of the seed that does not depend on how the ensemble is sharded.  Nothing is uploaded; ``kc`` ...
+        ``od_w`` are fetched from the device when read.  Call ``commit`` for the reset."""
+        net = self.net
+        eng = net._flush()
+        origins = [node for node in net.nodes.values() if node.virtual_incoming_link is not None and node.node_id in net.origin_nodes]
+        eng.randomize_scenarios(0 if seed is None else seed, link_fraction, links=True, od_weights=self._arr["od_w"] is not None,
+                                origin_nodes=[node.index for node in origins])
+        if int(len(self._pair_links) * link_fraction) > 0:
+            self._on_device |= {"kc", "kj", "vf", "fft", "tau_sw", "tt0"}
+        if self._arr["od_w"] is not None:
+            self._on_device.add("od_w")
+        ids = {node.node_id for node in origins}
+        self.demand = {key: v for key, v in self.demand.items() if key[0] not in ids}
+        for node in origins:
+            net._dirty_demand.discard(node)
+        self.link_params_dirty = self.od_dirty = False
+
+    def draw_random_host(self, seed, link_fraction=0.2):
+        """``draw_random`` in numpy on the host (six [L, R] uploads; 19-24 ms for 2048 envs where the device version takes < 1 ms):
+        kept as the cross-check of the device kernels' distributions.
+        A new scenario for EVERY replica, drawn for all replicas at once from the distributions of the reference's
         randomisers: ``generate_random_link_params`` (env_loader.py:363-424: ``link_fraction`` of the corridors; with
         probability 1/2 k_critical and k_jam scaled by U(0.6, 1.2) with the floors max(0.5, .) / max(2 k_c, .); with
         probability 1/2 free_flow_speed scaled by U(0.6, 0.9)), ``generate_random_od_flows`` (:224-259: U(1, 10) per OD pair)
@@ -237,3 +272,18 @@ class ScenarioBatch:
         net._invalidate()
         if reset:
             net.reset()
+
+
+def _matrix_property(name):
+    def get(self):
+        return self._matrix(name)
+
+    def put(self, value):
+        self._on_device.discard(name)
+        self._arr[name] = value
+
+    return property(get, put)
+
+
+for _name in ("kc", "kj", "vf", "fft", "tau_sw", "tt0", "od_w"):
+    setattr(ScenarioBatch, _name, _matrix_property(_name))

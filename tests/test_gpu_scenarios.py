@@ -287,3 +287,99 @@ def test_short_demand_rows_of_a_subset_replace_the_whole_row():
             mine = e.read_block(LINK_FIELDS[nm][0], 0, 150, rep0=r, rep1=r + 1)[:, :, 0].T
             assert np.array_equal(mine[:e.n_links], o.field(nm)[:e.n_links, :150]), (r, nm)
     net.close()
+
+
+def test_link_parameter_records_round_trip_and_device_derivation():
+    """pedn_set_link_params packs six [L, R] matrices into one 32-byte record per (link, replica) on the device and
+    pedn_get_link_params unpacks them: bit for bit what went in.  The randomiser derives travel_time[0] and the two look-backs on
+    the device (make_link_pr): equal to scenarios.derive_statics_arrays -- the reference's expressions -- applied to what it drew."""
+    from pednstream_amd.scenarios import derive_statics_arrays
+
+    R = 200                                                 # not a multiple of 128: padding lanes exist
+    np.random.seed(2)
+    net = NetworkEnvGenerator(DATA).create_network("nine_intersections", verbose=False, n_replicas=R, rng_seed=0)
+    e = net.engine()
+    L = net.n_links
+    rng = np.random.default_rng(5)
+    kc, vf = rng.uniform(0.5, 3.0, (L, R)), rng.uniform(0.5, 2.0, (L, R))
+    kj = kc * rng.uniform(2.0, 4.0, (L, R))
+    fft, tsw = rng.integers(0, 3000, (L, R)).astype(np.int32), rng.integers(0, 3000, (L, R)).astype(np.int32)
+    tt0 = rng.uniform(1.0, 4000.0, (L, R)).astype(np.float32)
+    e.set_link_params(kc, kj, vf, fft, tsw, tt0)
+    got = e.get_link_params()
+    for name, want in (("kc", kc), ("kj", kj), ("vf", vf), ("fft", fft), ("tau_sw", tsw), ("tt0", tt0)):
+        assert got[name].dtype == want.dtype and np.array_equal(got[name], want), name
+    with pytest.raises(Exception):
+        e.set_link_params(kc, kj, vf, fft + 40000, tsw, tt0)             # beyond the 16 bits of the record
+    batch = ScenarioBatch(net)
+    batch.draw_random(11)
+    length = np.array([l.length for l in net._link_list], dtype=np.float64)[:, None]
+    tt0_h, fft_h, tsw_h = derive_statics_arrays(length, batch.vf, batch.kc, batch.kj, net.unit_time)
+    assert np.array_equal(batch.tt0, tt0_h) and np.array_equal(batch.fft, fft_h) and np.array_equal(batch.tau_sw, tsw_h)
+    net.close()
+
+
+def test_device_randomiser_draws_the_distributions_of_the_host_generator():
+    """pedn_randomize_scenarios against ScenarioBatch.draw_random_host (numpy, the distributions of env_loader.py:183-259,363-424):
+    exactly k corridors per env can change and every corridor is equally likely; factor means and variances; OD weights; demand
+    patterns and levels; per-replica OD tables equal to the host derivation from the same weights."""
+    B = 2048
+    np.random.seed(4)
+    net = NetworkEnvGenerator(DATA).create_network("45_intersections", verbose=False, n_replicas=B, rng_seed=0)
+    e = net.engine()
+    dev, host = ScenarioBatch(net), ScenarioBatch(net)
+    dev.draw_random(123)
+    P = len(dev._pair_links)
+    k = int(P * 0.2)
+    kc0, kj0, vf0 = (dev._base[n][:, None] for n in ("kc", "kj", "vf"))
+    pair_of_link = np.empty(net.n_links, dtype=np.int64)
+    for p, links in enumerate(dev._pair_links.values()):
+        for l in links:
+            pair_of_link[l.index] = p
+
+    def summary(b):
+        dens, spd = b.kc != kc0, b.vf != vf0
+        assert np.array_equal(dens, b.kj != kj0) or np.all((b.kj != kj0) <= dens)
+        touched = np.zeros((P, B), dtype=bool)
+        np.logical_or.at(touched, pair_of_link, dens | spd)
+        # both directions of a corridor change together
+        for links in b._pair_links.values():
+            i, j = links[0].index, links[1].index
+            assert np.array_equal(dens[i], dens[j]) and np.array_equal(spd[i], spd[j])
+        f = (b.kc / kc0)[dens]
+        g = (b.vf / vf0)[spd]
+        return touched, f, g
+
+    t_d, f_d, g_d = summary(dev)
+    assert t_d.sum(axis=0).max() <= k and abs(t_d.sum(axis=0).mean() - 0.75 * k) < 0.15          # P(changes | chosen) = 3/4
+    per_corridor = t_d.sum(axis=1) / B                                                          # every corridor: 0.75 k / P
+    assert abs(per_corridor.mean() - 0.75 * k / P) < 0.004 and per_corridor.std() < 3.5 * np.sqrt(0.75 * k / P / B)
+    assert 0.6 <= f_d.min() and f_d.max() <= 1.2 and abs(f_d.mean() - 0.9) < 0.004 and abs(f_d.var() - 0.03) < 0.002   # U(0.6, 1.2)
+    assert 0.6 <= g_d.min() and g_d.max() <= 0.9 + 1e-12 and abs(g_d.mean() - 0.75) < 0.0035 and abs(g_d.var() - 0.0075) < 0.0005
+    np.random.seed(4)
+    host.draw_random_host(123)
+    t_h, f_h, g_h = summary(host)
+    assert abs(t_d.mean() - t_h.mean()) < 0.003 and abs(f_d.mean() - f_h.mean()) < 0.006 and abs(g_d.mean() - g_h.mean()) < 0.003
+    w = dev.od_w
+    n_w = w.size                                                             # U(1, 10): mean 5.5, variance 6.75, 4th central moment 82.0
+    assert w.shape == host.od_w.shape and 1.0 <= w.min() and w.max() < 10.0
+    assert abs(w.mean() - 5.5) < 4.5 * np.sqrt(6.75 / n_w) and abs(w.var() - 6.75) < 4.5 * np.sqrt((82.0 - 6.75 ** 2) / n_w)
+    assert len({w[:, r].tobytes() for r in range(B)}) == B
+    # demand: a third of the (origin, env) pairs constant, levels inside the randomiser's ranges
+    T = net.simulation_steps
+    origin = next(n for n in net.nodes.values() if n.virtual_incoming_link is not None and n.node_id in net.origin_nodes)
+    rows = np.stack([e.get_demand(origin.index, r) for r in range(0, B, 4)])
+    const = np.all(rows[:, :T] == rows[:, :1], axis=1) & (rows[:, 0] != np.floor(rows[:, 0]))
+    assert abs(const.mean() - 1 / 3) < 0.07 and np.all((rows[const, 0] >= 2.0) & (rows[const, 0] < 10.0))
+    assert rows.min() >= 0 and 4.0 < rows[~const, :T].mean() < 14.0
+    # the tables of P(od | up) derived on the device == the host path fed with the same weights (bit for bit: same operations)
+    net.reset(); net.run(1, 12)
+    hist_dev = {f: e.read_block(LINK_FIELDS[f][0], 0, 12, rep0=0, rep1=64) for f in ("inflow", "density")}
+    tfd = [np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 1, B - 1)]
+    e.set_od_weights_per_replica(w)
+    net.reset(); net.run(1, 12)
+    for f in hist_dev:
+        assert np.array_equal(hist_dev[f], e.read_block(LINK_FIELDS[f][0], 0, 12, rep0=0, rep1=64)), f
+    for a, b in zip(tfd, [np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 1, B - 1)]):
+        assert np.array_equal(a, b)
+    net.close()

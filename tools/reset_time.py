@@ -42,7 +42,28 @@ def main():
         print(f"  {label:58s} {min(ts) * 1e3:9.1f} ms (best of 3: {', '.join(f'{x * 1e3:.1f}' for x in ts)})")
 
     timed("reset()")
-    timed("reset(options={'randomize': True, 'mode': 'vectorised'})", options={"randomize": True, "mode": "vectorised"}, seed=1)
+    timed("reset(options={'randomize': True, 'mode': 'vectorised'})  [device]", options={"randomize": True, "mode": "vectorised"}, seed=1)
+    timed("reset(options={'randomize': True, 'mode': 'vectorised_host'})  [numpy]", options={"randomize": True, "mode": "vectorised_host"}, seed=1)
+
+    def piece(label, fn, n=5):
+        ts = []
+        for _ in range(n):
+            e.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            e.synchronize()
+            ts.append(time.perf_counter() - t0)
+        print(f"    {label:56s} {min(ts) * 1e3:9.2f} ms")
+
+    net = env.network
+    origins = [nd.index for nd in net.nodes.values() if nd.virtual_incoming_link is not None and nd.node_id in net.origin_nodes]
+    piece("pedn_randomize_scenarios: link parameters", lambda: e.randomize_scenarios(3, 0.2, links=True, od_weights=False))
+    piece("pedn_randomize_scenarios: OD weights + tables", lambda: e.randomize_scenarios(3, 0.2, links=False, od_weights=True))
+    piece(f"pedn_randomize_scenarios: demand of {len(origins)} origins", lambda: e.randomize_scenarios(3, 0.2, links=False, od_weights=False, origin_nodes=origins))
+    piece("pedn_reset (histories)", lambda: e.reset())
+    piece("four width matrices up (set_widths, before round 4)", lambda: [e.set_widths(code, net._widths[w]) for w, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3))])
+    piece("pedn_reset_widths (initial widths broadcast on the device)", lambda: e.reset_widths(net._widths["front"][:, 0], net._widths["back"][:, 0], net._widths["sep"][:, 0]))
+    piece("first observation fetched", lambda: e.rl_observe(1, accumulate=False))
     timed("reset(options={'randomize': True})  [reference streams]", options={"randomize": True}, seed=1)
     T = env.simulation_steps
     t0 = time.perf_counter()
