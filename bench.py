@@ -13,18 +13,28 @@ shape is --replicas 512 on 8 GPUs); --total-replicas M: M replicas in all, M / N
 
 value = links x replicas(all ranks) x K / wall-seconds (max over ranks) of the timed region; inputs are resident in
 HBM before the region starts.  The line also carries
-  roofline     dominant kernel (node_kernel).  `traffic` = memory-side bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-               passes of this same command, run as child processes BEFORE this process touches the GPU (N = 1; the committed
-               profiles/ summary of the same workload otherwise).  `achieved` / `frac` = those MOVED bytes / the launch's duration
-               (dispatch timestamps) vs 8 TB/s; the contract figure (ALGORITHMIC bytes per launch, 164 B per link-update, / the same
-               duration) is `achieved_algorithmic` / `frac_algorithmic` -- and is what `achieved` / `frac` fall back to for a workload
-               without counter passes, live or committed (`basis` says which of the three).  `working_set_bytes_per_step` + `fits_infinity_cache`: whether "hbm"
-               means HBM for this batch; the whole step is `whole_step_frac` (212 B per link-update) / `whole_step_frac_counter`
+  launch_plan  how pedn_run stepped (pedn_plan_info): chains of launches, and whether the link update of step t is performed by the
+               slot waves of step t + 1's node kernel (ONE launch per step) -- the default for models without device-computed
+               turning fractions, the headline among them
+  roofline     dominant kernel (node_kernel).  ONE fixed basis (`basis_kind`: "algorithmic"): `achieved` / `frac` = SURVEY 8(d)'s
+               contract bytes per launch (212 B per link-update when the node kernel performs the link update too, 164 B otherwise)
+               / the launch's duration (dispatch timestamps) vs 8 TB/s.  Beside it: `traffic` / `frac_counter` = memory-side bytes
+               per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, run as child processes BEFORE
+               this process touches the GPU (N = 1; the committed profiles/ summary of the same workload otherwise; null when there
+               is neither); `algorithmic_bytes_executed` / `frac_executed` = the contract's bytes on the paths this workload
+               really takes (the four diffusion look-backs only where get_outflow runs, widths every replica shares as scalar
+               loads, the gate record only where it changes), tallied by the oracle over the replicas cpu_baseline ran;
+               `working_set_bytes_per_step` + `fits_infinity_cache`: whether "hbm" means HBM for this batch; the whole step is
+               `whole_step_frac` (212 B per link-update) / `whole_step_frac_counter`
+  headline_long_window   the same measurement over 300 steps after 100 when the command's own --steps is shorter
   cpu_baseline the C restatement under oracle/ timed on this host's cores (1 thread and all cores, CPU model stated) on a
                bounded sample of the same workload + the derived reference-Python equivalent (profiles/cpu_calibration.json)
   extra        measured in the same run (N = 1 only; --no-extra skips them): BASELINE config #3 (delft x 1024); the headline
-               network at 4096 replicas (working set beyond the Infinity Cache) with its own counter passes; BASELINE config #5
-               (45_intersections x 2048 envs, batched RL step, env-steps/s) with a shared scenario and with per-env randomised ones
+               network at 4096 replicas (working set beyond the Infinity Cache) with its own counter passes; the headline network
+               under 12 x demand (the congested regime: release draws, diffusion look-backs and divergence fire); BASELINE config
+               #2's shape (nine_intersections x 256); BASELINE config #5 (45_intersections, batched RL step, env-steps/s) with a
+               shared scenario and with per-env randomised ones, at 2048 / 4096 / 8192 envs, and SUSTAINED over whole episodes with
+               the resets inside the timed region
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment starts its N ranks itself (torch.distributed.run as a
 child process, before anything touches the GPU) and exits with the child's code; a WORLD_SIZE that disagrees with --gpus
@@ -67,8 +77,9 @@ def cpu_model_name():
     return "unknown"
 
 
-def _oracle_rate(model, net, origin_nodes, threads, seconds_target, key0=0):
-    """Oracle (C restatement) on `threads` host threads, one replica per thread, full episodes, for ~seconds_target."""
+def _oracle_rate(model, net, origin_nodes, threads, seconds_target, key0=0, demand_scale=1.0):
+    """Oracle (C restatement) on `threads` host threads, one replica per thread, full episodes, for ~seconds_target.
+    Also returns the oracle's tallies of the paths cal_sending_flow took (summed over the replicas run)."""
     import oracle_driver as od
 
     T = int(model["T"])
@@ -80,19 +91,38 @@ def _oracle_rate(model, net, origin_nodes, threads, seconds_target, key0=0):
             key = key0 + rounds * threads + i
             o.reset(seed=0, replica=key)
             for nid in origin_nodes:
-                o.set_demand(net.nodes[nid].index, replica_demand(T, key))
+                o.set_demand(net.nodes[nid].index, replica_demand(T, key, base=5.0 * demand_scale, peak=10.0 * demand_scale))
         od.run_many(oracles, 1, T)
         done += threads
         rounds += 1
         el = time.perf_counter() - t0
         if el >= seconds_target or rounds >= 64:
             break
+    tally = np.sum([o.tally() for o in oracles], axis=0)
     for o in oracles:
         o.close()
-    return done * (T - 1) * int(model["n_links"]) / el, done, el
+    return done * (T - 1) * int(model["n_links"]) / el, done, el, tally
 
 
-def cpu_baseline(model, net, origin_nodes, network, seconds_target=7.0):
+def executed_bytes(tally, shared_widths=True, gate_changes=False):
+    """SURVEY 8(d)'s 212 B per link-update restricted to the paths the workload takes.  The contract counts, per link-update: the
+    four inflow look-backs of get_outflow (32 B) -- read only where the sending flow is positive on a free-flowing link
+    (tally[3] of tally[0] calls); front and back gate widths (16 B) -- one scalar load per wave when every replica shares them;
+    the gate record (8 B written) -- stored only where it differs from the link's width; density[t'] (4 B) -- recomputed from
+    num_pedestrians with the link update's own division, never read; num_pedestrians of the reverse link twice (sending and
+    receiving side, 8 B) -- read once."""
+    calls = float(tally[0])
+    p_diff = float(tally[3]) / calls if calls else 0.0
+    b = 212.0 - 32.0 * (1.0 - p_diff) - 4.0 - 4.0
+    if shared_widths:
+        b -= 16.0
+    if not gate_changes:
+        b -= 8.0
+    return b, {"sending_flow_calls": int(tally[0]), "past_free_flow_gate": int(tally[1]), "positive_before_draw": int(tally[2]),
+               "diffusion_lookbacks_read": int(tally[3]), "activity_draws": int(tally[4]), "p_diffusion": p_diff}
+
+
+def cpu_baseline(model, net, origin_nodes, network, seconds_target=7.0, demand_scale=1.0):
     """the C restatement on this host, 1 thread and all cores, with the CPU named; and the
     reference-Python equivalent derived through the ratio tools/calibrate_cpu.py measured where the reference lives."""
     cores = os.cpu_count() or 1
@@ -101,12 +131,16 @@ def cpu_baseline(model, net, origin_nodes, network, seconds_target=7.0):
     except (AttributeError, OSError):
         usable = cores
     T = int(model["T"])
-    one, n1, s1 = _oracle_rate(model, net, origin_nodes, 1, seconds_target)
-    alln, na, sa = _oracle_rate(model, net, origin_nodes, usable, seconds_target, key0=10000)
+    one, n1, s1, t1 = _oracle_rate(model, net, origin_nodes, 1, seconds_target, demand_scale=demand_scale)
+    alln, na, sa, ta = _oracle_rate(model, net, origin_nodes, usable, seconds_target, key0=10000, demand_scale=demand_scale)
+    ex_bytes, ex_detail = executed_bytes(t1 + ta)
     out = {"value": alln, "unit": "link-updates/s", "cores": usable, "kind": "port",
            "sample": f"{na} replicas x {T - 1} steps of {network} on {usable} host threads ({sa:.1f} s) and {n1} replicas on 1 thread "
                      f"({s1:.1f} s); oracle/pedn_oracle.c, one replica per thread, same per-replica demand and RNG keys as the GPU run",
-           "one_thread": one, "all_cores": alln, "cores_total": cores, "cores_usable": usable, "cpu_model": cpu_model_name()}
+           "one_thread": one, "all_cores": alln, "cores_total": cores, "cores_usable": usable, "cpu_model": cpu_model_name(),
+           # which paths of cal_sending_flow those replicas took over their whole episodes (engine == oracle bit for bit, so these are
+           # the GPU's own branch statistics for the same replicas): the contract's 212 B on executed paths
+           "algorithmic_bytes_executed_per_link_update": ex_bytes, "executed_paths": ex_detail}
     cal = os.path.join(ROOT, "profiles", "cpu_calibration.json")
     if os.path.exists(cal):
         with open(cal) as f:
@@ -144,6 +178,7 @@ def live_traffic(workloads, history):
         return
     tmp = tempfile.mkdtemp(prefix="pedn_pmc_", dir="/tmp")
     env = dict(os.environ, PEDN_BENCH_CHILD="1", TMPDIR="/tmp")
+    deadline = time.perf_counter() + float(os.environ.get("PEDN_BENCH_PMC_BUDGET_S", "240"))   # for ALL passes: the headline line must not wait on a slow profiler
 
     def counters(counter, tag, cmd):
         d = os.path.join(tmp, tag)
@@ -151,8 +186,9 @@ def live_traffic(workloads, history):
         # left on the GPU when the timed run starts
         proc = subprocess.Popen([roc, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env,
                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        left = deadline - time.perf_counter()
         try:
-            rc = proc.wait(timeout=150)
+            rc = proc.wait(timeout=max(5.0, min(120.0, left)))
         except subprocess.TimeoutExpired:
             os.killpg(proc.pid, signal.SIGKILL)
             proc.wait()
@@ -169,7 +205,10 @@ def live_traffic(workloads, history):
         cal = [sys.executable, os.path.join(ROOT, "tools", "pmc_calibrate.py")]
         fetch_factor = round(2 * (1 << 26) * 8 / (counters("FETCH_SIZE", "cf", cal)["device_math_kernel"][0] * 1024), 2)
         write_factor = round((1 << 26) * 8 / (counters("WRITE_SIZE", "cw", cal)["device_math_kernel"][0] * 1024), 2)
-        for network, replicas in workloads:
+        for network, replicas in workloads:      # the headline first; the extras only while the budget lasts
+            if deadline - time.perf_counter() < 45:
+                print(f"bench.py: PMC budget spent, no live passes for {network} x {replicas}", file=sys.stderr)
+                break
             cmd = [sys.executable, os.path.abspath(__file__), "--network", network, "--replicas", str(replicas), "--history", history,
                    "--steps", "48", "--warmup", "20", "--no-cpu-baseline", "--no-extra"]
             f, w = counters("FETCH_SIZE", f"pf_{network}_{replicas}", cmd), counters("WRITE_SIZE", f"pw_{network}_{replicas}", cmd)
@@ -185,7 +224,7 @@ def live_traffic(workloads, history):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024):
+def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024, plan=None):
     """Memory-side bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN[_network]_pmc.json, written by
     tools/summarize_profiles.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  bench.py cannot
     collect PMC counters on itself: the number rides along, labelled with its file, only for the workload it was measured on."""
@@ -202,6 +241,10 @@ def measured_traffic(kernel="node_kernel", network="melbourne", replicas=1024):
         return None, None
     with open(files[-1]) as f:
         d = json.load(f)
+    # a committed summary stands in only when it was taken under the launch plan of this run (round 4 changed the default plan: bytes
+    # per launch of node_kernel under the owner-wave plan / two chains are not those of earlier rounds)
+    if plan is not None and d.get("launch_plan") != {k: plan[k] for k in ("chains", "link_update_by_next_node_kernel")}:
+        return None, None
     for name, k in d.get("kernels", {}).items():
         if name.startswith(kernel):
             return k["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
@@ -269,6 +312,51 @@ def measure_rl(network, B, steps, warmup, history, randomized=False):
     return out
 
 
+def sustained_rl(network, B, history, mode, episodes=3):
+    """Config #5 as a training loop runs it: `episodes` whole episodes of T - 1 env steps each, every one started by a reset INSIDE the
+    timed region (rl/pz_pednet_env.py:143-193): mode "plain" = reset(); "vectorised" = reset(options={'randomize': True, 'mode':
+    'vectorised'}) -- every env a new scenario drawn on the device (pedn_randomize_scenarios); "reference" = the same with the
+    reference's randomisers, one np.random stream consumed env after env on the host (bit-exact goldens, host-bound)."""
+    import torch
+
+    from pednstream_amd.rl_env import VecPedNetEnv
+
+    env = VecPedNetEnv(network, n_envs=B, obs_mode="option3", action_gap=1, seed=0, data_dir=os.path.join(ROOT, "data"), history=history)
+    e = env.network.engine()
+    T = env.simulation_steps
+    K = T - 1
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    hi = torch.as_tensor(env.action_high, device="cuda", dtype=torch.float64)
+    acts = torch.rand((K, B, env.n_actions), generator=gen, device="cuda", dtype=torch.float64) * hi
+    torch.cuda.synchronize()
+    row = B * env.n_actions * 8
+    options = None if mode == "plain" else {"randomize": True, "mode": "vectorised" if mode == "vectorised" else "reference"}
+
+    def episode(seed):
+        e.synchronize()               # the previous episode's steps were enqueued asynchronously: let them finish before timing the reset
+        t0 = time.perf_counter()
+        env.reset(options=options, seed=seed)
+        e.synchronize()
+        t_reset = time.perf_counter() - t0
+        for k in range(K):
+            e.rl_step_device(acts.data_ptr() + k * row, k + 1)
+        return t_reset
+
+    np.random.seed(0)
+    episode(100)                      # warm-up episode (first use of the per-replica kernels, allocations)
+    e.synchronize()
+    t0 = time.perf_counter()
+    resets = [episode(101 + i) for i in range(episodes)]
+    e.synchronize()
+    wall = time.perf_counter() - t0
+    rc, _ = e.error_flags()
+    assert rc == 0
+    env.close()
+    return {"value": B * K * episodes / wall, "unit": "env-steps/s", "episodes": episodes, "env_steps_per_episode": K, "n_envs": B,
+            "wall_s": wall, "reset_ms_mean": float(np.mean(resets)) * 1e3, "reset_share_of_wall": float(np.sum(resets)) / wall,
+            "history": history, "reset": mode}
+
+
 def bench_rl(args):
     print(json.dumps(measure_rl(args.network, args.replicas, args.steps, args.warmup, args.history, args.randomize)), flush=True)
 
@@ -287,8 +375,9 @@ def spawn_ranks(args, argv):
     return subprocess.call(cmd)
 
 
-def measure(args, network, dist, rank, local_rank, world):
-    """Warm-up, the timed region, per-kernel durations; returns (fields of the JSON line, net, engine-side context)."""
+def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
+    """Warm-up, the timed region, per-kernel durations; returns (fields of the JSON line, net, engine-side context).
+    demand_scale: the origin demand of every replica times this (12: the congested regime of the goldens melbourne_heavy_*)."""
     from pednstream_amd import NetworkEnvGenerator
     from pednstream_amd.ensemble import shard
 
@@ -307,7 +396,7 @@ def measure(args, network, dist, rank, local_rank, world):
     e = net.engine()
     origins = list(net.origin_nodes)
     for nid in origins:                        # one upload per origin: [R, T] rows keyed by the global replica id
-        net.set_demand_matrix(nid, np.stack([replica_demand(T, offset + r) for r in range(R)]))
+        net.set_demand_matrix(nid, np.stack([replica_demand(T, offset + r, base=5.0 * demand_scale, peak=10.0 * demand_scale) for r in range(R)]))
     e.synchronize()
     L = e.n_links
 
@@ -359,17 +448,32 @@ def measure(args, network, dist, rank, local_rank, world):
     # per-launch durations (the dispatches' own start / stop timestamps) under the SAME launch plan as the timed region, continuing
     # the same simulation.  chains = 2: run() launched the two halves of the replicas as two chains on two streams; a launch then
     # covers R / 2 replicas and overlaps the other chain's launches.
+    def union_ms(iv):
+        """Total length of the union of the intervals (start, end): the time during which at least one of the launches was running."""
+        total, cur_a, cur_b = 0.0, None, None
+        for a, b in sorted(iv):
+            if cur_b is None or a > cur_b:
+                total += 0.0 if cur_b is None else cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        return total + (0.0 if cur_b is None else cur_b - cur_a)
+
     def profile(n):
+        """Per-launch means of the three kinds of launch, the number of chains, and the node kernel's BUSY time per step: the union of
+        its launches' [start, end] intervals / n (one chain: the sum of its launch durations; two chains: their launches overlap)."""
         if state["t"] + n >= T - 1:
             e.reset()
             e.step(1)                 # the first step of an episode carries the stand-alone turning-fraction launch
             state["t"] = 2
-        ms, ch = e.profile_run(state["t"], state["t"] + n)
+        rows, ch = e.profile_timeline(state["t"], state["t"] + n)
         state["t"] += n
-        return ms, ch
+        ms = [float(np.mean(rows[rows[:, 2] == k, 4] - rows[rows[:, 2] == k, 3])) if np.any(rows[:, 2] == k) else 0.0 for k in range(3)]
+        node_rows = rows[rows[:, 2] == 1]
+        return ms, ch, union_ms([(a, b) for a, b in node_rows[:, 3:5]]) / n
 
     n_prof = min(40, max(8, args.steps // 8))
-    (tf_ms, node_ms, link_ms), chains = profile(n_prof)
+    (tf_ms, node_ms, link_ms), chains, node_busy_ms = profile(n_prof)
     plan = e.plan_info()
     owner = plan["link_update_by_next_node_kernel"]
     if owner:
@@ -381,7 +485,7 @@ def measure(args, network, dist, rank, local_rank, world):
     if chains == 2 and not args.no_extra:
         # the same kernels launched over the whole batch, one chain on one stream: what a launch achieves on its own
         e.set_streams(1)
-        (tf1, node1, link1), _ = profile(n_prof)
+        (tf1, node1, link1), _, _ = profile(n_prof)
         if owner:
             link1 = link1 / n_prof
         e.set_streams(2)
@@ -415,24 +519,26 @@ def measure(args, network, dist, rank, local_rank, world):
     # time the machine spends on one step of all replicas: one chain -> the sum of its launches (gaps excluded); two chains ->
     # their launches overlap, so the device time of the timed region (HIP events around it) per step
     step_ms = node_ms + link_ms + tf_ms if chains == 1 else dev_ms / args.steps
-    achieved_alg = node_bytes / (node_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic("node_kernel", network, R)     # per launch, measured under this same plan
+    # the dominant kernel against the roofline: its contract bytes of one step (all chains) over the time per step during which it was
+    # running (one chain: = bytes per launch / mean launch duration; two chains: their launches overlap, each sharing the machine with
+    # the other chain's -- the per-launch quotient alone would describe half a machine)
+    achieved_alg = node_kernel_bytes * L * R / (node_busy_ms * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic("node_kernel", network, R, plan)     # per launch, measured under this same plan
     live = traffic is not None and traffic_src.startswith("live")
     # the second launch's memory-side bytes, for the working set of a step
     traffic2 = None
     for k2 in ("link_turn_kernel", "link_kernel_1r", "link_kernel"):
-        t2, _ = measured_traffic(k2, network, R)
+        t2, _ = measured_traffic(k2, network, R, plan)
         if t2 is not None:
             traffic2 = t2
             break
-    # `achieved` / `frac`: bytes the memory side MOVED for the launch (FETCH_SIZE + WRITE_SIZE) over its duration when the PMC passes
-    # of this run succeeded -- the kernel moves fewer bytes than the contract counts (shared widths and static fractions are scalar
-    # loads, cumulative_*[t-1] is reused), so the contract figure over the same duration would overstate what the memory system did;
-    # that figure stays beside it as `achieved_algorithmic` / `frac_algorithmic`.
-    # Without live passes (N > 1, --no-live-traffic) the per-launch bytes of the committed passes of the same workload stand in -- the
-    # traffic of a launch does not vary from run to run (112.4..112.9 MB over the round) -- and `basis` says so; with neither, both
-    # pairs are the contract's.
-    achieved = traffic / (node_ms * 1e-3) / 1e9 if traffic is not None else achieved_alg
+    # `achieved` / `frac` stay on ONE basis in every run and on every rank: the contract's algorithmic bytes per launch over the launch's
+    # duration (`basis_kind`).  What the memory side MOVED for the launch (FETCH_SIZE + WRITE_SIZE) rides beside it as `traffic` /
+    # `frac_counter` (null without counter passes, live or committed), and the contract's bytes on executed paths as `frac_executed`
+    # (filled in from cpu_baseline's tallies).
+    achieved = achieved_alg
+    if owner:
+        traffic2 = 0.0               # one launch per step: the range's single trailing link_kernel is not part of a step's working set
     working_set = None if traffic is None or traffic2 is None else (traffic + traffic2) * chains
     mdl = e.model
     n_dyn_turns = int(np.diff(mdl["node_turn_ptr"])[np.asarray(mdl["node_dyn"]) > 0].sum())     # +8 B each per replica
@@ -445,15 +551,23 @@ def measure(args, network, dist, rank, local_rank, world):
                    "replicas_per_gpu": R, "replicas_total": R * world, "links": L,
                    "parallelism": f"replica-sharded x{world}, no step-path collective"},
         "device_ms_per_step": dev_ms / args.steps,
-        "roofline": {"bound": "hbm", "kernel": "node_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "basis": ("bytes moved: rocprofv3 FETCH_SIZE + WRITE_SIZE of this run per launch / the launch's duration" if live else
-                               "bytes moved per launch in the COMMITTED rocprofv3 FETCH_SIZE + WRITE_SIZE passes of this workload (traffic_source) / "
-                               "this run's launch duration (no live counter passes in this run)" if traffic is not None else
-                               "algorithmic bytes per launch / the launch's duration (no counter passes for this workload, live or committed)"),
+        "roofline": {"bound": "hbm",
+                     "kernel": ("node_kernel<LU>: sending / receiving flows, node model, cumulative counts AND the link update of the previous step "
+                                "(one launch per step)" if owner else "node_kernel: sending / receiving flows, node model, cumulative counts"),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "basis_kind": "algorithmic",
+                     "basis": f"SURVEY 8(d) contract bytes of the kernel's launches of one step ({node_kernel_bytes} B per link-update x {L * R} "
+                              "link-updates) / the time per step during which the kernel was running = the union of its launches' dispatch "
+                              "intervals (pedn_profile_timeline; with one chain of launches that is bytes per launch / mean launch duration) -- "
+                              "the same basis in every run; the bytes the memory side moved are `traffic` / `frac_counter`, the contract's "
+                              "bytes on executed paths `frac_executed`",
+                     "kernel_busy_ms_per_step": float(node_busy_ms),
+                     "per_launch": {"algorithmic_bytes": node_bytes, "avg_ms": float(node_ms), "GBps": node_bytes / (node_ms * 1e-3) / 1e9,
+                                    "note": "one launch = replicas / concurrent_chains; under two chains it shares the machine with the other chain's launch"},
                      "achieved_algorithmic": achieved_alg, "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
+                     "traffic_is_live": bool(live),
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "frac_counter": None if traffic is None else traffic / (node_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "frac_counter": None if traffic is None else traffic * chains / (node_busy_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic_bytes_per_link_update": None if traffic is None else traffic * chains / (L * R),
                      # what one step touches, and whether "hbm" means HBM: a step whose working set fits the 256 MB Infinity Cache is
                      # served from it between the launches (FETCH_SIZE counts those hits too)
@@ -541,13 +655,25 @@ def main():
     out, net, origins = measure(args, args.network, dist, rank, local_rank, world)
     if out["ranks_seen"] != world:
         raise SystemExit(f"only {out['ranks_seen']} of {world} ranks took part")
+
+    def add_executed(line, cb):
+        """The contract's bytes on the paths the workload takes (cpu_baseline's tallies) next to the contract figure."""
+        bx = cb["algorithmic_bytes_executed_per_link_update"]
+        rf = line["roofline"]
+        rf["algorithmic_bytes_executed_per_link_update"] = bx
+        rf["frac_executed"] = rf["whole_step_frac"] * bx / BYTES_PER_LINK_UPDATE
+        rf["executed_basis"] = ("whole step: 212 B per link-update minus the bytes of paths this workload does not take (bench.py: executed_bytes; "
+                                "tallied by the oracle over the replicas cpu_baseline ran, whole episodes) over the step's device time")
+
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flatten_network(net), net, origins, args.network)
+            add_executed(out, out["cpu_baseline"])
     net.close()
-    if rank == 0 and world == 1 and not args.no_extra and args.network == "melbourne" and args.replicas == 1024 and not args.total_replicas:
+    headline = args.network == "melbourne" and args.replicas == 1024 and not args.total_replicas
+    if rank == 0 and world == 1 and not args.no_extra and headline:
         import copy
-        keep = ("value", "unit", "ms_per_step", "device_ms_per_step", "config", "roofline")
+        keep = ("value", "unit", "ms_per_step", "device_ms_per_step", "steps", "warmup", "config", "roofline")
         out["extra"] = {}
 
         def extra(name, fn):
@@ -557,31 +683,44 @@ def main():
             except (Exception, SystemExit) as exc:    # noqa: BLE001  (measure() leaves through SystemExit when error flags are set)
                 out["extra"][name] = {"error": f"{type(exc).__name__}: {exc}"}
 
-        def config3():
-            # BASELINE config #3 (the network BASELINE.json names for the rocprof roofline), same engine, same run
-            ex, net3, origins3 = measure(args, "delft", None, 0, local_rank, 1)
+        def variant(network, replicas=1024, steps=None, warmup=None, demand_scale=1.0, cpu_seconds=0.0):
+            a2 = copy.copy(args)
+            a2.replicas, a2.no_extra = replicas, True
+            a2.steps, a2.warmup = steps or args.steps, warmup or args.warmup
+            ex, net2, origins2 = measure(a2, network, None, 0, local_rank, 1, demand_scale=demand_scale)
             try:
-                if not args.no_cpu_baseline:
-                    ex["cpu_baseline"] = cpu_baseline(flatten_network(net3), net3, origins3, "delft", seconds_target=4.0)
+                if cpu_seconds and not args.no_cpu_baseline:
+                    ex["cpu_baseline"] = cpu_baseline(flatten_network(net2), net2, origins2, network, seconds_target=cpu_seconds, demand_scale=demand_scale)
+                    add_executed(ex, ex["cpu_baseline"])
             finally:
-                net3.close()
+                net2.close()
             return {k: ex[k] for k in keep + (("cpu_baseline",) if "cpu_baseline" in ex else ())}
 
-        def hbm_proper():
-            # the same headline network with a working set beyond the 256 MB Infinity Cache (4096 replicas: the per-GPU shape of nothing
-            # in BASELINE, but the point where "hbm" means HBM), with its own counter passes
-            a4 = copy.copy(args)
-            a4.replicas, a4.steps, a4.warmup, a4.no_extra = 4096, min(args.steps, 120), min(args.warmup, 30), True
-            ex4, net4, _ = measure(a4, "melbourne", None, 0, local_rank, 1)
-            net4.close()
-            return {k: ex4[k] for k in keep}
-
-        extra("config3_delft_x1024", config3)
-        extra("hbm_proper_melbourne_x4096", hbm_proper)
-        # BASELINE config #5: the batched RL env step on 45_intersections x 2048 envs, shared scenario and per-env randomised scenarios
+        if args.steps < 300:
+            # the driver's window (--steps 20 after 5) is a few hundred microseconds at the empty start of an episode: the same
+            # measurement over the builder's window, in the same run
+            extra("headline_long_window", lambda: variant("melbourne", steps=300, warmup=100))
+        # BASELINE config #3 (the network BASELINE.json names for the rocprof roofline), same engine, same run
+        extra("config3_delft_x1024", lambda: variant("delft", cpu_seconds=4.0))
+        # the same headline network with a working set beyond the 256 MB Infinity Cache (4096 replicas: the per-GPU shape of nothing
+        # in BASELINE, but the point where "hbm" means HBM), with its own counter passes
+        extra("hbm_proper_melbourne_x4096", lambda: variant("melbourne", replicas=4096, steps=min(args.steps, 120), warmup=min(args.warmup, 30)))
+        # the congested regime: 12 x the origin demand per replica (the goldens melbourne_heavy_*): release binomials, get_outflow's
+        # look-backs, the congested branch of the sending flow and divergence between lanes all fire
+        extra("melbourne_heavy_x1024", lambda: variant("melbourne", steps=max(args.steps, 200), warmup=max(args.warmup, 150), demand_scale=12.0, cpu_seconds=3.0))
+        # BASELINE config #2's shape
+        extra("nine_x256", lambda: variant("nine_intersections", replicas=256, steps=max(args.steps, 200), warmup=max(args.warmup, 100)))
+        # BASELINE config #5: the batched RL env step on 45_intersections, shared scenario and per-env randomised scenarios
         extra("config5_rl_45int_x2048", lambda: {
             "plain": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=False),
-            "randomized": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=True)})
+            "randomized": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=True),
+            # where the env step stops being latency-bound: more envs per launch (recent-history mode: 8192 envs are 16 GB)
+            "by_n_envs_recent_history": {str(n): {k: v for k, v in measure_rl("45_intersections", n, args.steps, args.warmup, "recent", randomized=False).items()
+                                                  if k in ("value", "unit", "device_ms_per_step", "whole_step_frac", "steps")}
+                                         for n in (2048, 4096, 8192)},
+            # whole episodes WITH their resets (rl/pz_pednet_env.py:143-193 resets every episode)
+            "sustained": {f"{mode}_{hist}": sustained_rl("45_intersections", 2048, hist, mode)
+                          for hist in ("full", "recent") for mode in ("plain", "vectorised", "reference")}})
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

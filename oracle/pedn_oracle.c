@@ -200,6 +200,10 @@ struct pedn_oracle {
   uint32_t replica;
   int mode;
   uint32_t flags;
+  /* which paths of cal_sending_flow ran since the last reset (bench.py: the contract's bytes on EXECUTED paths): [0] calls,
+   * [1] past the free-flow gate (link.py:267-269), [2] sending flow positive before the draw (:298), [3] get_outflow's four
+   * inflow look-backs read (:323, :199-214), [4] activity draw (:351-358) */
+  uint64_t tally[5];
   /* histories */
   double* f64[7]; /* [Lall][T1] for 0..3, [L][T1] for 4..6 */
   float* f32[6];  /* [L][T1]: tt, att, N, k, v, lf */
@@ -333,7 +337,9 @@ static double send_flow(pedn_oracle* o, int l, int tp) {
   float dens = dens_of(o, l, tp);
   float att = G(o, G_ATT, l)[tp];
   int tau = (int)lrintf(att / (float)m->dt); /* link.py:260, round-half-even of an f32 */
+  o->tally[0]++;
   if (tp < m->link_fft[l]) { S[tp] = 0.0; return 0.0; } /* link.py:267-269 */
+  o->tally[1]++;
   if (tau <= 0) o->flags |= PEDN_F_SAME_STEP;
   int idx = tp + 1 - tau; if (idx < 0) idx = 0; /* link.py:274 */
   double kc = m->link_kc[l], kj = m->link_kj[l], vf = m->link_vf[l];
@@ -348,11 +354,13 @@ static double send_flow(pedn_oracle* o, int l, int tp) {
   double orig = s;
   rng_key key = {o->seed, o->replica, (uint32_t)l, (uint32_t)tp, 0};
   if (s > 0.0) {
+    o->tally[2]++;
     float rf = clip01(dens / (float)kj);                                 /* link.py:315 */
     float p = 0.7f + (float)(0.85 - 0.7) * pw_powf(rf, 0.8f);            /* link.py:317 */
     int diffusion_used = 0;
     if (dens <= (float)kc) {                                             /* link.py:323 */
       /* get_outflow, link.py:199-214 */
+      o->tally[3]++;
       float F = 1.0f / (1.0f + (float)m->link_gamma[l] * att);
       float Gq = 1.0f - F;
       const double* in = H(o, F_IN, l);
@@ -374,6 +382,7 @@ static double send_flow(pedn_oracle* o, int l, int tp) {
     if (s < 0.0) o->flags |= PEDN_F_NEG_SENDING;
   }
   if (m->link_act[l] > 0.0 && s > 1.0) { /* link.py:351-358 */
+    o->tally[4]++;
     key.site = 1;
     s -= (double)rng_binomial((int64_t)floor(s), m->link_act[l], &key, o->mode);
   }
@@ -730,6 +739,7 @@ const void* pedn_oracle_field(pedn_oracle* o, int field) {
   return field < 7 ? (const void*)o->f64[field] : (const void*)o->f32[field - 7];
 }
 uint32_t pedn_oracle_flags(pedn_oracle* o) { return o->flags; }
+void pedn_oracle_tally(pedn_oracle* o, uint64_t out[5]) { memcpy(out, o->tally, sizeof(o->tally)); }
 float pedn_oracle_powf(float x, float y) { return pw_powf(x, y); }
 double pedn_oracle_exp(double x) { return pw_exp(x); }
 void pedn_oracle_philox(uint32_t ctr[4], uint32_t k0, uint32_t k1) { philox4x32_10(ctr, k0, k1); }

@@ -48,6 +48,8 @@ def lib():
         L.pedn_oracle_field.argtypes = [P, C.c_int]
         L.pedn_oracle_flags.restype = C.c_uint32
         L.pedn_oracle_flags.argtypes = [P]
+        L.pedn_oracle_tally.restype = None
+        L.pedn_oracle_tally.argtypes = [P, C.POINTER(C.c_uint64)]
         L.pedn_oracle_powf.restype = C.c_float
         L.pedn_oracle_powf.argtypes = [C.c_float, C.c_float]
         L.pedn_oracle_exp.restype = C.c_double
@@ -98,6 +100,13 @@ class Oracle:
 
     def flags(self):
         return int(self.L.pedn_oracle_flags(self.h))
+
+    def tally(self):
+        """Paths of cal_sending_flow taken since the oracle was created (resets keep counting): calls, past the free-flow gate,
+        positive before the draw, diffusion look-backs read, activity draws."""
+        out = (C.c_uint64 * 5)()
+        self.L.pedn_oracle_tally(self.h, out)
+        return [int(x) for x in out]
 
     def set_demand(self, node_index, values):
         v = np.ascontiguousarray(values, dtype=np.float64)
