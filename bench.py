@@ -448,20 +448,8 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
     # per-launch durations (the dispatches' own start / stop timestamps) under the SAME launch plan as the timed region, continuing
     # the same simulation.  chains = 2: run() launched the two halves of the replicas as two chains on two streams; a launch then
     # covers R / 2 replicas and overlaps the other chain's launches.
-    def union_ms(iv):
-        """Total length of the union of the intervals (start, end): the time during which at least one of the launches was running."""
-        total, cur_a, cur_b = 0.0, None, None
-        for a, b in sorted(iv):
-            if cur_b is None or a > cur_b:
-                total += 0.0 if cur_b is None else cur_b - cur_a
-                cur_a, cur_b = a, b
-            else:
-                cur_b = max(cur_b, b)
-        return total + (0.0 if cur_b is None else cur_b - cur_a)
-
     def profile(n):
-        """Per-launch means of the three kinds of launch, the number of chains, and the node kernel's BUSY time per step: the union of
-        its launches' [start, end] intervals / n (one chain: the sum of its launch durations; two chains: their launches overlap)."""
+        """Per-launch mean durations (dispatch timestamps) of the three kinds of launch, and the number of chains."""
         if state["t"] + n >= T - 1:
             e.reset()
             e.step(1)                 # the first step of an episode carries the stand-alone turning-fraction launch
@@ -469,11 +457,10 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
         rows, ch = e.profile_timeline(state["t"], state["t"] + n)
         state["t"] += n
         ms = [float(np.mean(rows[rows[:, 2] == k, 4] - rows[rows[:, 2] == k, 3])) if np.any(rows[:, 2] == k) else 0.0 for k in range(3)]
-        node_rows = rows[rows[:, 2] == 1]
-        return ms, ch, union_ms([(a, b) for a, b in node_rows[:, 3:5]]) / n
+        return ms, ch
 
     n_prof = min(40, max(8, args.steps // 8))
-    (tf_ms, node_ms, link_ms), chains, node_busy_ms = profile(n_prof)
+    (tf_ms, node_ms, link_ms), chains = profile(n_prof)
     plan = e.plan_info()
     owner = plan["link_update_by_next_node_kernel"]
     if owner:
@@ -485,7 +472,7 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
     if chains == 2 and not args.no_extra:
         # the same kernels launched over the whole batch, one chain on one stream: what a launch achieves on its own
         e.set_streams(1)
-        (tf1, node1, link1), _, _ = profile(n_prof)
+        (tf1, node1, link1), _ = profile(n_prof)
         if owner:
             link1 = link1 / n_prof
         e.set_streams(2)
@@ -519,9 +506,11 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
     # time the machine spends on one step of all replicas: one chain -> the sum of its launches (gaps excluded); two chains ->
     # their launches overlap, so the device time of the timed region (HIP events around it) per step
     step_ms = node_ms + link_ms + tf_ms if chains == 1 else dev_ms / args.steps
-    # the dominant kernel against the roofline: its contract bytes of one step (all chains) over the time per step during which it was
-    # running (one chain: = bytes per launch / mean launch duration; two chains: their launches overlap, each sharing the machine with
-    # the other chain's -- the per-launch quotient alone would describe half a machine)
+    # The dominant kernel against the roofline: its contract bytes of one step (all chains) over ITS SHARE of the step's machine time =
+    # step_ms x (its launch duration / the sum of the step's launch durations).  One chain: step_ms is that sum, so this is bytes per
+    # launch / mean launch duration.  Two chains: the launches of the two chains overlap and share the machine, so a launch's own
+    # duration describes half a machine; the unperturbed device time per step is apportioned among the kernels by their durations.
+    node_busy_ms = step_ms * node_ms / (node_ms + link_ms + tf_ms)
     achieved_alg = node_kernel_bytes * L * R / (node_busy_ms * 1e-3) / 1e9
     traffic, traffic_src = measured_traffic("node_kernel", network, R, plan)     # per launch, measured under this same plan
     live = traffic is not None and traffic_src.startswith("live")
@@ -557,10 +546,11 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "basis_kind": "algorithmic",
                      "basis": f"SURVEY 8(d) contract bytes of the kernel's launches of one step ({node_kernel_bytes} B per link-update x {L * R} "
-                              "link-updates) / the time per step during which the kernel was running = the union of its launches' dispatch "
-                              "intervals (pedn_profile_timeline; with one chain of launches that is bytes per launch / mean launch duration) -- "
-                              "the same basis in every run; the bytes the memory side moved are `traffic` / `frac_counter`, the contract's "
-                              "bytes on executed paths `frac_executed`",
+                              "link-updates) / the kernel's share of the step's machine time = device time per step x (its mean launch duration / "
+                              "the sum of the step's mean launch durations; dispatch timestamps, pedn_profile_timeline).  With one chain of launches "
+                              "that is bytes per launch / mean launch duration; with two chains the launches overlap and share the machine.  The "
+                              "same basis in every run; the bytes the memory side moved are `traffic` / `frac_counter`, the contract's bytes on "
+                              "executed paths `frac_executed`",
                      "kernel_busy_ms_per_step": float(node_busy_ms),
                      "per_launch": {"algorithmic_bytes": node_bytes, "avg_ms": float(node_ms), "GBps": node_bytes / (node_ms * 1e-3) / 1e9,
                                     "note": "one launch = replicas / concurrent_chains; under two chains it shares the machine with the other chain's launch"},

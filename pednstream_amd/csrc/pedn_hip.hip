@@ -33,6 +33,7 @@ struct pedn_sim {
   int node_waves = 8, node_waves_pr = 6;  // register budget of node_kernel (waves per SIMD) with shared / per-replica link parameters, see pedn_create
   int lu_waves = 8, lu_waves_pr = 6;      // the same for the instantiation that performs the link update (node_kernel<LU>)
   int link_owner = 0;  // pedn_run: node_kernel(t + 1)'s slot waves perform the link update of t (one launch per step), PEDN_LINK_OWNER
+  int rl_owner = 0;    // pedn_rl_step under the owner-wave plan (PEDN_RL_OWNER)
   int link_pending = -1;  // owner-wave plan: step whose link update has not been performed yet, -1 none
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
   // The link update as a launch of its own runs one replica per lane (link_kernel_1r: 42-47 VGPRs, 8 waves per SIMD; melbourne x 1024
@@ -371,6 +372,7 @@ extern "C" {
 
 static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows, size_t row0, size_t row_stride, int replica);
 static void flush_links(pedn_sim* s, int half, hipEvent_t* ev);
+static inline void pending_links_first(pedn_sim* s);
 
 int pedn_abi_version(void) { return PEDN_ABI_VERSION; }
 
@@ -775,6 +777,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // a node of 7 or 8 corridors (the instantiation unrolled for 8): 4..8 vector spills at 8 waves, none at 6
     s->node_waves = s->max_degree <= 6 ? 8 : 6;
     s->node_waves_pr = 6;
+    // (the node LP, assign_flows_type 'optimal', is built for 6 waves only -- at 8 it spills 4..14 vector registers -- and ignores this)
     if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = s->node_waves_pr = atoi(w) == 6 ? 6 : 8;
     s->lu_waves = s->node_waves; s->lu_waves_pr = s->node_waves_pr;
     if (const char* w = getenv("PEDN_LU_WAVES")) s->lu_waves = s->lu_waves_pr = atoi(w) == 6 ? 6 : 8;
@@ -798,6 +801,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // link-update workgroups that leave it save (delft x 1024: 42.1-42.6 -> 44.2).  PEDN_LINK_OWNER=0|1 overrides.
     s->link_owner = v.n_trow == 0 && m->node_model != PEDN_NODE_OPTIMAL;
     if (const char* f = getenv("PEDN_LINK_OWNER")) s->link_owner = atoi(f) != 0;
+    if (const char* f = getenv("PEDN_RL_OWNER")) s->rl_owner = atoi(f) != 0;
     s->node_lp = m->node_model == PEDN_NODE_OPTIMAL;
     if (s->node_lp) {  // tableau workspace: one per (regular node, replica group), sized for the largest such node
       int n_lp = 0, max_m = 0;
@@ -1080,6 +1084,8 @@ int pedn_set_width(pedn_sim* s, int32_t which, int32_t link, int32_t replica, do
   if (link < 0 || link >= s->v.L || which < 0 || which > 3) return fail(s, PEDN_E_ARG, "link or selector out of range");
   double* dst = which == PEDN_W_FRONT ? s->v.front : which == PEDN_W_BACK ? s->v.back : which == PEDN_W_SEP ? s->v.sepw : s->v.sepnp;
   if (which == PEDN_W_BACK) s->tp_ready = -1;  // capacity fallback of the turn probabilities (path_finder.py:575-576)
+  hipSetDevice(s->device);
+  pending_links_first(s);     // the link update records the gate / reads the separator width of its own step
   int rc = push_rows(s, dst, &value, 1, (size_t)link, 1, replica);
   if (rc != PEDN_OK || which > PEDN_W_BACK) return rc;
   (which == PEDN_W_FRONT ? s->h_front_u : s->h_back_u)[link] = replica == PEDN_ALL ? value : __builtin_nan("");
@@ -1094,6 +1100,7 @@ int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {
   if (v.L == 0) return PEDN_OK;
   double* dst = which == PEDN_W_FRONT ? v.front : which == PEDN_W_BACK ? v.back : which == PEDN_W_SEP ? v.sepw : v.sepnp;
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   size_t bytes = (size_t)v.L * v.R * 8;
   pedn_sim::Stage* st;
   int rc = stage_acquire(s, bytes, &st);
@@ -1121,7 +1128,7 @@ int pedn_reset_widths(pedn_sim* s, const double* front, const double* back, cons
   s->tp_ready = -1;
   if (v.L == 0) return PEDN_OK;
   HIP_TRY(s, hipSetDevice(s->device));
-  flush_links(s, -1, nullptr);
+  pending_links_first(s);
   int rc;
   if ((rc = push_rows(s, v.front, front, v.L, 0, 1, PEDN_ALL)) || (rc = push_rows(s, v.back, back, v.L, 0, 1, PEDN_ALL)) ||
       (rc = push_rows(s, v.sepw, sep, v.L, 0, 1, PEDN_ALL)))
@@ -1206,6 +1213,12 @@ static void flush_links(pedn_sim* s, int half, hipEvent_t* ev) {
 // t+1 (models with softmax groups) and the RL observations / rewards of t (observe >= 0: the accumulate flag of
 // rl_observe; only pedn_rl_step asks for it).  ev != nullptr: per-launch start/stop events {turn_prob, node, link} for
 // pedn_profile_step.  Returns 1 through *observed when the observations were part of the launch.
+// Every entry point that looks at or changes what a link update reads or writes calls this first: under the owner-wave plan the link
+// update of the last step launched may still be pending (link_pending) -- the next step's node kernel would perform it.
+static inline void pending_links_first(pedn_sim* s) {
+  if (s->link_pending >= 0) flush_links(s, -1, nullptr);
+}
+
 // lazy (owner-wave plan, pedn_run): the link update of t is left to node_kernel<LU>(t + 1) -- or to flush_links -- and this step's
 // node_kernel performs the pending one of t - 1.
 static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe = -1, bool* observed = nullptr,
@@ -1283,7 +1296,9 @@ int pedn_step(pedn_sim* s, int32_t t) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
-  launch_step(s, t);
+  // owner-wave plan: this step's link update stays pending -- the next step's node kernel performs it, or whatever call looks at
+  // or changes the state first (pending_links_first)
+  launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, s->link_owner != 0);
   HIP_TRY(s, hipGetLastError());
   return PEDN_OK;
 }
@@ -1336,7 +1351,7 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
   // several steps take this plan; everything else (single steps, RL steps, profiling) stays on the one stream.
   // Owner-wave plan (link_owner): one launch per step for models without dynamic turning fractions -- node_kernel<LU>(t) performs the
   // link update of t - 1 -- plus one link_kernel for the last step of the range.
-  const bool lazy = s->link_owner != 0 && t1 - t0 >= 2;
+  const bool lazy = s->link_owner != 0;
   if (two_chains(s, t0, t1)) {
     HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
     HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
@@ -1344,13 +1359,10 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
       launch_step(s, t, nullptr, -1, nullptr, nullptr, 0, lazy);
       launch_step(s, t, nullptr, -1, nullptr, nullptr, 1, lazy);
     }
-    flush_links(s, 0, nullptr);
-    flush_links(s, 1, nullptr);
-    const int rc = join_chains(s);
+    const int rc = join_chains(s);    // the last step's link update stays pending on the joined stream (pending_links_first)
     if (rc != PEDN_OK) return rc;
   } else {
     for (int t = t0; t < t1; ++t) launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, lazy);
-    flush_links(s, -1, nullptr);
   }
   HIP_TRY(s, hipGetLastError());
   return PEDN_OK;
@@ -1384,7 +1396,7 @@ struct ProfRow { int t, chain, kind; float start, end; };
 static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows, int* chains) {
   const bool two = two_chains(s, t0, t1);
   const int halves = two ? 2 : 1, n = (t1 - t0) * halves;
-  const bool lazy = s->link_owner != 0 && t1 - t0 >= 2;   // pedn_run's plan
+  const bool lazy = s->link_owner != 0;   // pedn_run's plan
   struct Events {  // destroyed on every way out of the function
     std::vector<hipEvent_t> e;
     ~Events() { for (hipEvent_t x : e) if (x) hipEventDestroy(x); }
@@ -1472,6 +1484,7 @@ int pedn_profile_timeline(pedn_sim* s, int32_t t0, int32_t t1, float* out, int32
 int pedn_synchronize(pedn_sim* s) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   return PEDN_OK;
 }
@@ -1479,6 +1492,7 @@ int pedn_synchronize(pedn_sim* s) {
 int pedn_error_flags(pedn_sim* s, uint32_t* flags) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   std::vector<uint32_t> h(s->v.RS);
   HIP_TRY(s, hipMemcpy(h.data(), s->v.flags, (size_t)s->v.RS * 4, hipMemcpyDeviceToHost));
@@ -1506,6 +1520,7 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
                                  " entries of this field; the newest is " + std::to_string(newest) + ")");
   }
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   size_t n = (size_t)(t1 - t0) * (c1 - c0) * (r1 - r0);
   size_t esz = field < 7 ? 8 : 4;
@@ -1528,6 +1543,7 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
 
 void* pedn_device_ptr(pedn_sim* s, int32_t field, int64_t* columns, int64_t* replica_stride) {
   if (!s || field < 0 || field >= PEDN_N_FIELDS) return nullptr;
+  if (s->link_pending >= 0 && hipSetDevice(s->device) == hipSuccess) pending_links_first(s);   // the consumer orders itself behind pedn_stream()
   if (columns) *columns = field < 4 ? s->v.Lall : s->v.L;
   if (replica_stride) *replica_stride = s->v.RS;
   return field < 7 ? (void*)s->v.f64[field] : (void*)s->v.f32[field - 7];
@@ -1543,6 +1559,7 @@ void* pedn_stream(pedn_sim* s) { return s ? (void*)s->stream : nullptr; }
 int pedn_timer_begin(pedn_sim* s) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipEventRecord(s->ev0, s->stream));
   return PEDN_OK;
 }
@@ -1550,6 +1567,7 @@ int pedn_timer_begin(pedn_sim* s) {
 int pedn_timer_end(pedn_sim* s, float* ms) {
   if (!s || !ms) return fail(s, PEDN_E_ARG, "null argument");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipEventRecord(s->ev1, s->stream));
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
@@ -1561,6 +1579,7 @@ int pedn_set_link_params(pedn_sim* s, const double* kc, const double* kj, const 
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   s->tp_ready = -1;
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   DevView& v = s->v;
   if (!kc) {  // back to the shared parameters
@@ -1656,7 +1675,7 @@ int pedn_randomize_scenarios(pedn_sim* s, uint64_t seed, double link_fraction, i
   if ((what & 4) && n_origins > 0 && !origin_nodes) return fail(s, PEDN_E_ARG, "origin nodes missing");
   HIP_TRY(s, hipSetDevice(s->device));
   DevView& v = s->v;
-  flush_links(s, -1, nullptr);
+  pending_links_first(s);
   s->tp_ready = -1;
   const uint32_t k0 = (uint32_t)(seed & 0xffffffffu), k1 = (uint32_t)(seed >> 32);
   int rc;
@@ -1798,6 +1817,7 @@ int pedn_rl_apply_actions(pedn_sim* s, const double* actions, int32_t on_device)
   if (!s || !actions) return fail(s, PEDN_E_ARG, "null argument");
   if (!s->rl_ready) return fail(s, PEDN_E_ARG, "pedn_rl_configure has not been called");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   DevView& v = s->v;
   RlView& q = s->rl;
   const size_t bytes = (size_t)v.R * q.A * sizeof(double);
@@ -1816,6 +1836,7 @@ int pedn_rl_observe(pedn_sim* s, int32_t t, int32_t accumulate, float* obs, floa
   if (!s->rl_ready) return fail(s, PEDN_E_ARG, "pedn_rl_configure has not been called");
   if (t < 0 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 0..T");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   DevView& v = s->v;
   RlView& q = s->rl;
   if (v.hist) hipLaunchKernelGGL(rl_observe_kernel<true>, dim3((unsigned)q.n_agents * (unsigned)(v.RS / 64)), dim3(256), 0, s->stream, v, q, t, accumulate);
@@ -1847,12 +1868,14 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
         HIP_TRY(s, hipStreamSynchronize(s->stream));  // the host buffer is borrowed for the call only
         fold = q.actions;
       }
-    } else if ((rc = pedn_rl_apply_actions(s, actions, on_device)) != PEDN_OK) return rc;
+    } else if ((rc = pedn_rl_apply_actions(s, actions, on_device)) != PEDN_OK) return rc;   // (performs a pending link update first)
   }
   for (int k = 0; k < action_gap; ++k) {
     const bool last = k == action_gap - 1;
     bool observed = false;
-    launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr);
+    // owner-wave plan of the RL step (rl_owner): only with the actions folded into node_kernel and the observations in the second launch
+    const bool lazy = s->rl_owner && s->rl_fold && s->fuse_obs && (!actions || fold != nullptr);
+    launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, -1, lazy);
     HIP_TRY(s, hipGetLastError());
     if (!observed) {
       if ((rc = pedn_rl_observe(s, t + k, k > 0, last ? obs : nullptr, last ? rewards : nullptr)) != PEDN_OK) return rc;

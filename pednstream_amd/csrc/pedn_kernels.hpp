@@ -836,6 +836,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       // independent of it) is drawn while it is in flight
       int idx_s = tp + 1 - __float2int_rn(x.att_in / (float)v.dt);  // link.py:260,274
       if (idx_s < 0) idx_s = 0;
+      if (idx_s > tp + 1) idx_s = tp + 1;   // a zero / negative / garbage avg_travel_time must not take the load past the rows written so far
       const double ci_look = v.f64[F_CI][at(R64(F_CI, idx_s), lin, Lall, RS, r)];
       const double rp = recv_reverse_peds(v, Pout, lout, tp, r, x, fl);
       s_i = early ? 0.0 : send_flow<HIST>(v, Pin, lin, tp, r, x, ci_look, fl);

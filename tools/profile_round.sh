@@ -29,7 +29,7 @@ profile() {  # $1 = suffix ("" or "_delft"), rest = bench arguments
   rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/sq4$SUF -- python3 $R/bench.py "$@" --steps 48 --warmup 20 --no-cpu-baseline --no-extra > $O/sq4$SUF.log 2>&1 || echo "SQ pass 4 failed (see sq4$SUF.log)"
   (cd $R && python3 tools/summarize_busy.py $O/sq3$SUF $O/sq4$SUF > $P/$TAG${SUF}_unit_busy.json) || true
   echo "SQ$SUF done"
-  (cd $R && python3 tools/summarize_profiles.py $TAG$SUF $O/kt$SUF $O/pf$SUF $O/pw$SUF $O/cf $O/cw 20)
+  (cd $R && python3 tools/summarize_profiles.py $TAG$SUF $O/kt$SUF $O/pf$SUF $O/pw$SUF $O/cf $O/cw 20 $O/kt$SUF.log)
   (cd $R && python3 tools/summarize_sq.py $O/sq1$SUF $O/sq2$SUF --skip 20 > $P/$TAG${SUF}_sq_counters.json) || true
   cp $R/profiles/$TAG${SUF}_kernel_stats.csv $R/profiles/$TAG${SUF}_pmc.json $P/
 }
@@ -84,6 +84,8 @@ if [ "$PART" = all ] || [ "$PART" = extras ]; then
   PEDN_FUSE_TP=0 python3 tools/turn_phase_profile.py delft >> $P/${TAG}_phase_profile.txt 2>> $O/bench.err
   python3 tools/turn_phase_profile.py delft | sed 's/^== /== (inside link_turn_kernel) /' >> $P/${TAG}_phase_profile.txt 2>> $O/bench.err
   python3 tools/dropin_time.py > $P/${TAG}_dropin_time.txt 2>> $O/bench.err
+  python3 tools/reset_time.py > $P/${TAG}_reset_time.txt 2>> $O/bench.err
+  python3 tools/reset_time.py 45_intersections 2048 recent >> $P/${TAG}_reset_time.txt 2>> $O/bench.err
   /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/xstream tools/xstream_bench.hip 2> /dev/null && timeout -k 5 60 /tmp/xstream > $P/${TAG}_cross_stream_dependency.txt 2>&1 || true
   /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -o /tmp/valu_rates tools/valu_rates.hip 2> /dev/null && timeout -k 5 60 /tmp/valu_rates > $P/${TAG}_valu_rates.txt 2>&1 || true
   # stream ceilings by footprint / mix / access width, the per-group barrier, the workgroup timeline of link_turn_kernel

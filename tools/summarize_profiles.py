@@ -1,6 +1,9 @@
 """Condense rocprofv3 outputs merged under gpurun_out/ into the small tracked files under profiles/.
 
-  python tools/summarize_profiles.py <round-tag> <kernel-trace-dir> <pmc-fetch-dir> <pmc-write-dir> <cal-fetch-dir> <cal-write-dir> [warmup]
+  python tools/summarize_profiles.py <round-tag> <kernel-trace-dir> <pmc-fetch-dir> <pmc-write-dir> <cal-fetch-dir> <cal-write-dir> [warmup] [bench-log]
+
+bench-log: stdout of the profiled bench.py run; its `roofline.launch_plan` goes into the summary, so that bench.py lets the summary
+stand in for live counter passes only under the same launch plan (chains, owner-wave link update).
 
 Writes profiles/<tag>_kernel_stats.csv (verbatim rocprofv3 --stats table) and profiles/<tag>_pmc.json with per-kernel
 HBM-side bytes per launch.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half of the bytes of a
@@ -58,6 +61,11 @@ for k in ("node_kernel", "link_kernel", "link_kernel_1r", "link_turn_kernel", "t
     summary["kernels"][k] = {"launches_averaged": len(fr), "FETCH_SIZE_KiB_mean": st.mean(fr), "WRITE_SIZE_KiB_mean": st.mean(wr),
                              "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wt,
                              "hbm_bytes_per_launch": rd + wt}
+if len(sys.argv) > 8 and os.path.exists(sys.argv[8]):
+    for line in open(sys.argv[8]):
+        if line.startswith("{"):
+            plan = json.loads(line)["roofline"].get("launch_plan", {})
+            summary["launch_plan"] = {k: plan.get(k) for k in ("chains", "link_update_by_next_node_kernel")}
 with open(os.path.join(out, f"{tag}_pmc.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
 print(json.dumps(summary, indent=1))
