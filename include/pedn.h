@@ -236,10 +236,12 @@ int pedn_profile_run(pedn_sim* sim, int32_t t0, int32_t t1, float ms[3], int32_t
  * `capacity` rows (3 per step and chain), *n_rows of them written.  Shows how the launches of the two chains overlap. */
 int pedn_profile_timeline(pedn_sim* sim, int32_t t0, int32_t t1, float* out, int32_t capacity, int32_t* n_rows, int32_t* chains);
 
-/* launch plan of pedn_run for long ranges: 1 = one chain of launches on the engine's stream, 2 = the two halves of the
- * replicas as two chains on two streams (the default from 1024 replicas; replicas are independent, results are the same) */
+/* launch plan of pedn_run for long ranges: 1 = one chain of launches on the engine's stream, 2 / 4 = the halves / quarters of the
+ * replicas as that many chains on as many streams (2 is the default from 1024 replicas; replicas are independent, results are the
+ * same).  The streams are probed to run side by side (pedn_plan_info); when the runtime cannot provide that many independent queues
+ * the plan falls back to the number it can (4 chains want GPU_MAX_HW_QUEUES >= 5 in the environment before the HIP runtime starts). */
 int pedn_set_streams(pedn_sim* sim, int32_t n);
-/* The launch plan of pedn_run: info[0] = chains (1 | 2), info[1] = 1 when the link update is performed by the next step's node kernel
+/* The launch plan of pedn_run: info[0] = chains (1 | 2 | 4), info[1] = 1 when the link update is performed by the next step's node kernel
  * (one launch per step), info[2] = streams created until one was found that overlaps with the engine's stream (0: not probed yet;
  * the runtime may map two streams onto one hardware queue, which would serialise the chains), info[3] = duration in microseconds of
  * the probe's two concurrent 300 us kernels on the pair kept (~300: they overlap, ~600: they do not); n = entries of info (>= 4). */

@@ -44,7 +44,11 @@ struct pedn_sim {
   int max_degree = 0;     // largest number of incident corridors of a node
   size_t node_lds = 0;    // dynamic LDS bytes of node_kernel
   hipStream_t stream2 = nullptr;   // second half of the replicas in pedn_run (two_streams)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t stream34[2] = {nullptr, nullptr};   // chains 2 and 3 of the four-chain plan (created when it is chosen)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join34[2] = {nullptr, nullptr};
+  int warmed_chains = 1;  // chains whose streams exist and were probed to overlap
+  int chains = 1;         // plan of pedn_run for long ranges: 1, 2 or 4 chains of launches (two_streams = chains > 1)
+  int run_chains = 1;     // chains of the range being launched (launch_step / flush_links: the last chain does the bookkeeping)
   int streams_probed = 0, stream_probe_attempts = 0;   // warm_second_stream: stream2 was checked to overlap with stream
   float stream_probe_ms = 0.0f;
   int two_streams = 0;    // pedn_run launches the two halves of the batch on two streams (replicas are independent)
@@ -169,45 +173,58 @@ static int stage_commit(pedn_sim* s, pedn_sim::Stage* st) {
 // step, delft 42.8 -> 64.8, profiles/r04_stream_queues.txt).  So the pairing is probed, not assumed: a 300 us spin on each stream,
 // timed together; while they do not overlap another candidate for stream2 is created (the rejected ones stay alive until the
 // search ends, so that the runtime moves on to its other queues).
-static int probe_overlap(pedn_sim* s, hipStream_t second, float* ms) {
+static hipStream_t chain_stream(const pedn_sim* s, int c) { return c <= 0 ? s->stream : c == 1 ? s->stream2 : s->stream34[c - 2]; }
+
+// a 300 us spin on the engine's stream and on chains 1..n-1 at once; *ms = how long all of them took together
+static int probe_overlap(pedn_sim* s, int n, float* ms) {
   HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
-  HIP_TRY(s, hipStreamWaitEvent(second, s->ev_fork, 0));
+  for (int c = 1; c < n; ++c) HIP_TRY(s, hipStreamWaitEvent(chain_stream(s, c), s->ev_fork, 0));
   HIP_TRY(s, hipEventRecord(s->ev0, s->stream));
-  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s->stream, 30000ull);   // ticks of the constant 100 MHz clock
-  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, second, 30000ull);
-  HIP_TRY(s, hipEventRecord(s->ev_join, second));
-  HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
+  for (int c = 0; c < n; ++c) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, chain_stream(s, c), 30000ull);   // ticks of the constant 100 MHz clock
+  for (int c = 1; c < n; ++c) {
+    hipEvent_t ev = c == 1 ? s->ev_join : s->ev_join34[c - 2];
+    HIP_TRY(s, hipEventRecord(ev, chain_stream(s, c)));
+    HIP_TRY(s, hipStreamWaitEvent(s->stream, ev, 0));
+  }
   HIP_TRY(s, hipEventRecord(s->ev1, s->stream));
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
   return PEDN_OK;
 }
-static int warm_second_stream(pedn_sim* s) {
-  HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
-  HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
-  hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, s->stream2);
-  HIP_TRY(s, hipEventRecord(s->ev_join, s->stream2));
-  HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
-  if (s->streams_probed) return PEDN_OK;
-  s->streams_probed = 1;
-  if (const char* f = getenv("PEDN_STREAM_PROBE")) if (atoi(f) == 0) return PEDN_OK;
-  std::vector<hipStream_t> rejected;
-  int rc = PEDN_OK;
-  for (int attempt = 0; attempt < 12; ++attempt) {
-    float ms = 0.0f;
-    rc = probe_overlap(s, s->stream2, &ms);   // the first pass pays for whatever the runtime sets up lazily
-    if (rc == PEDN_OK) rc = probe_overlap(s, s->stream2, &ms);
-    if (rc != PEDN_OK) break;
-    s->stream_probe_ms = ms;
-    s->stream_probe_attempts = attempt + 1;
-    if (ms < 0.45f) break;        // overlapped: 0.3 ms + overheads; one behind the other: 0.6 ms
-    hipStream_t next = nullptr;
-    if (hipStreamCreateWithFlags(&next, hipStreamNonBlocking) != hipSuccess) break;   // keep what we have
-    rejected.push_back(s->stream2);
-    s->stream2 = next;
+// Streams for `want` chains (2 or 4), each probed to overlap with the ones before it; returns through *got how many chains have
+// streams that really run side by side (the plan falls back to that many).
+static int warm_chain_streams(pedn_sim* s, int want, int* got) {
+  *got = 1;
+  for (int c = 2; c < want; ++c) {   // chains 2, 3: created on demand
+    if (!s->stream34[c - 2]) HIP_TRY(s, hipStreamCreateWithFlags(&s->stream34[c - 2], hipStreamNonBlocking));
+    if (!s->ev_join34[c - 2]) HIP_TRY(s, hipEventCreateWithFlags(&s->ev_join34[c - 2], hipEventDisableTiming));
   }
+  bool probe = true;
+  if (const char* f = getenv("PEDN_STREAM_PROBE")) probe = atoi(f) != 0;
+  std::vector<hipStream_t> rejected;
+  int rc = PEDN_OK, attempts = 0;
+  for (int n = 2; n <= want && rc == PEDN_OK; ++n) {   // chain n - 1 against chains 0 .. n - 2
+    bool ok = !probe;
+    for (int attempt = 0; attempt < 10 && !ok && rc == PEDN_OK; ++attempt) {
+      float ms = 0.0f;
+      rc = probe_overlap(s, n, &ms);   // the first pass pays for whatever the runtime sets up lazily (queue creation: ~0.2 ms)
+      if (rc == PEDN_OK) rc = probe_overlap(s, n, &ms);
+      if (rc != PEDN_OK) break;
+      ++attempts;
+      s->stream_probe_ms = ms;
+      if (ms < 0.45f) { ok = true; break; }        // overlapped: 0.3 ms + overheads; one behind another: >= 0.6 ms
+      hipStream_t next = nullptr;
+      if (hipStreamCreateWithFlags(&next, hipStreamNonBlocking) != hipSuccess) break;   // keep what we have
+      hipStream_t& slot = n == 2 ? s->stream2 : s->stream34[n - 3];
+      rejected.push_back(slot);
+      slot = next;
+    }
+    if (!ok) break;
+    *got = n;
+  }
+  if (probe) s->stream_probe_attempts = attempts;
   for (hipStream_t x : rejected) hipStreamDestroy(x);
+  if (!probe) *got = want;
   return rc;
 }
 
@@ -724,6 +741,29 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     if (by_load)
       for (int n = 0; n < N; ++n) load[n] = m->turn_pair_ptr[m->node_turn_ptr[n + 1]] - m->turn_pair_ptr[m->node_turn_ptr[n]];
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] != load[b] ? load[a] > load[b] : deg(a) > deg(b); });
+    // PEDN_PACK_ORDER=1 (a diagnostic): nodes in breadth-first order over the network instead, so that the two end nodes of a corridor
+    // sit in blocks that are dispatched close together (both read the corridor's flows of the last step under the owner-wave plan)
+    if (const char* f = getenv("PEDN_PACK_ORDER")) if (atoi(f) == 1) {
+      std::vector<int> start_of(m->n_links + m->n_vlinks, -1);
+      for (int n = 0; n < N; ++n)
+        for (int k = m->node_slot_ptr[n]; k < m->node_slot_ptr[n + 1]; ++k) start_of[m->slot_out_link[k]] = n;
+      std::vector<char> seen(N, 0);
+      std::vector<int> bfs;
+      for (int root = 0; root < N; ++root) {
+        if (seen[root]) continue;
+        seen[root] = 1;
+        bfs.push_back(root);
+        for (size_t h = bfs.size() - 1; h < bfs.size(); ++h) {
+          const int n = bfs[h];
+          for (int k = m->node_slot_ptr[n]; k < m->node_slot_ptr[n + 1]; ++k) {
+            const int lin = m->slot_in_link[k];
+            const int u = lin < L ? start_of[lin] : -1;
+            if (u >= 0 && !seen[u]) { seen[u] = 1; bfs.push_back(u); }
+          }
+        }
+      }
+      order = bfs;
+    }
     std::vector<std::vector<int>> bins;
     std::vector<int> fill;
     for (int n : order) {
@@ -792,8 +832,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // with dynamic turning-fraction rows from 1024 replicas -- their second launch is few long waves at 4 waves per SIMD, and the
     // other half's node_kernel fills the machine meanwhile (delft x 1024: 51.7 -> 45.3 us per step).  Without such rows the gain
     // is smaller (melbourne 38.8 -> 37.3) and the plan stays one chain, whose launches are the ones the roofline figures describe.
-    s->two_streams = v.RS >= 1024;
-    if (const char* f = getenv("PEDN_STREAMS")) s->two_streams = atoi(f) == 2;
+    s->chains = v.RS >= 1024 ? 2 : 1;
+    if (const char* f = getenv("PEDN_STREAMS")) s->chains = atoi(f) == 4 ? 4 : atoi(f) == 2 ? 2 : 1;
+    s->two_streams = s->chains > 1;
     // Owner-wave plan of pedn_run (launch_step: lazy): node_kernel<LU>(t + 1) performs the link update of t, one launch per step.  The
     // default for models whose second launch is the link update alone (no turning fractions computed on the device): melbourne x 1024
     // 37.4 -> 32.7-33.7 us per step on one chain, 34.6 -> 30.3 on two (profiles/r04_owner_wave.txt).  With dynamic rows the second launch
@@ -870,7 +911,12 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     if (rc != PEDN_OK) { std::string keep = g_last_error; pedn_destroy(s); g_last_error = keep; return rc; }
   }
   HIP_TRY(s, hipStreamSynchronize(s->stream));
-  if (s->two_streams) TRY(warm_second_stream(s));
+  if (s->chains > 1) {
+    int got = 1;
+    TRY(warm_chain_streams(s, s->chains, &got));
+    s->chains = s->warmed_chains = got == 3 ? 2 : got;
+    s->two_streams = s->chains > 1;
+  }
 #undef TRY
   *out = s;
   return PEDN_OK;
@@ -889,6 +935,10 @@ int pedn_destroy(pedn_sim* s) {
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream2) hipStreamDestroy(s->stream2);
+  for (int k = 0; k < 2; ++k) {
+    if (s->stream34[k]) hipStreamDestroy(s->stream34[k]);
+    if (s->ev_join34[k]) hipEventDestroy(s->ev_join34[k]);
+  }
   if (s->ev_fork) hipEventDestroy(s->ev_fork);
   if (s->ev_join) hipEventDestroy(s->ev_join);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -1189,16 +1239,18 @@ static void launch_link_update(pedn_sim* s, const DevView& v, hipStream_t stream
 }
 
 // this launch's share of the batch: the whole of it on the engine's stream (half = -1) or one half of the replicas per stream
+// (half = index of the chain, 0 .. run_chains - 1: chain c steps replicas [c, c + 1) * RS / run_chains on its own stream)
 static DevView view_of(const pedn_sim* s, int half, hipStream_t* stream) {
   DevView v = s->v;
   *stream = s->stream;
   if (half >= 0) {
-    v.subRS = s->v.RS / 2;
+    v.subRS = s->v.RS / s->run_chains;
     v.sub0 = half * v.subRS;
-    if (half == 1) *stream = s->stream2;
+    *stream = chain_stream(s, half);
   }
   return v;
 }
+static inline bool last_chain(const pedn_sim* s, int half) { return half < 0 || half == s->run_chains - 1; }
 
 // Owner-wave plan: the link update of the last step launched is still to be done (link_pending); do it now.
 static void flush_links(pedn_sim* s, int half, hipEvent_t* ev) {
@@ -1206,7 +1258,7 @@ static void flush_links(pedn_sim* s, int half, hipEvent_t* ev) {
   hipStream_t stream;
   const DevView v = view_of(s, half, &stream);
   launch_link_update(s, v, stream, s->link_pending, ev, 4);
-  if (half != 0) s->link_pending = -1;
+  if (last_chain(s, half)) s->link_pending = -1;
 }
 
 // One step = node_kernel(t), then ONE launch with the link update of t and -- where they apply -- the turn probabilities of
@@ -1257,7 +1309,7 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0 && !obs_fused) ? 2 : 1;   // (the diagnostic NS = 2 has no OBS instantiation)
   const bool one_r = v.pr || (s->link_ns == 0 && !fused && !obs_fused);   // one replica per lane (link_kernel_1r)
   const unsigned nlb = lazy ? 0u : link_blocks(s, v, one_r, ns);   // lazy: no link-update workgroups in this step's second launch
-  if (half != 0) s->link_pending = lazy ? t : -1;
+  if (last_chain(s, half)) s->link_pending = lazy ? t : -1;
   s->second_launch = 1;
   if (fused || obs_fused) {
     const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u;
@@ -1279,13 +1331,13 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
       else PEDN_LT(false, false, 1);
     }
 #undef PEDN_LT
-    if (fused && half != 0) s->tp_ready = t + 1;   // half 0: the second half of this step still has to see the old value
+    if (fused && last_chain(s, half)) s->tp_ready = t + 1;   // the other chains of this step still have to see the old value
   } else if (nlb > 0) {
     launch_link_update(s, v, stream, t, ev, 4);
   }
   else s->second_launch = 0;
   if (observed) *observed = obs_fused;
-  if (half != 0) {
+  if (last_chain(s, half)) {
     s->last_t = t;
     ++s->step_epoch;
   }
@@ -1323,20 +1375,31 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   return PEDN_OK;
 }
 
-// pedn_run's plan for the range [t0, t1): the two halves of the batch as two chains of launches?
-static bool two_chains(const pedn_sim* s, int t0, int t1) {
-  return s->two_streams && t1 - t0 >= 8 && s->v.RS % 256 == 0;
+// pedn_run's plan for the range [t0, t1): how many chains of launches (each a share of the replicas on its own stream)?
+static int chains_for(const pedn_sim* s, int t0, int t1) {
+  if (s->chains < 2 || t1 - t0 < 8) return 1;
+  if (s->chains == 4 && s->v.RS % 512 == 0) return 4;
+  return s->v.RS % 256 == 0 ? 2 : 1;
 }
 
-// Join of the two chains of launches: the engine's stream waits for everything enqueued on stream2.  If the event path fails the
-// streams are drained instead, so that no call ever returns with work on stream2 that the engine's stream does not order.
-static int join_chains(pedn_sim* s) {
-  hipError_t e = hipEventRecord(s->ev_join, s->stream2);
-  if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->ev_join, 0);
+// Fork: every other chain's stream waits for what the engine's stream holds so far.
+static int fork_chains(pedn_sim* s, int n) {
+  HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
+  for (int c = 1; c < n; ++c) HIP_TRY(s, hipStreamWaitEvent(chain_stream(s, c), s->ev_fork, 0));
+  return PEDN_OK;
+}
+// Join of the chains of launches: the engine's stream waits for everything enqueued on the other streams.  If the event path fails
+// the streams are drained instead, so that no call ever returns with work on them that the engine's stream does not order.
+static int join_chains(pedn_sim* s, int n) {
+  hipError_t e = hipSuccess;
+  for (int c = 1; c < n && e == hipSuccess; ++c) {
+    hipEvent_t ev = c == 1 ? s->ev_join : s->ev_join34[c - 2];
+    e = hipEventRecord(ev, chain_stream(s, c));
+    if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, ev, 0);
+  }
   if (e != hipSuccess) {
-    hipStreamSynchronize(s->stream2);
-    hipStreamSynchronize(s->stream);
-    return fail(s, PEDN_E_DEVICE, std::string("joining the two chains of launches: ") + hipGetErrorString(e));
+    for (int c = n - 1; c >= 0; --c) hipStreamSynchronize(chain_stream(s, c));
+    return fail(s, PEDN_E_DEVICE, std::string("joining the chains of launches: ") + hipGetErrorString(e));
   }
   return PEDN_OK;
 }
@@ -1352,14 +1415,16 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
   // Owner-wave plan (link_owner): one launch per step for models without dynamic turning fractions -- node_kernel<LU>(t) performs the
   // link update of t - 1 -- plus one link_kernel for the last step of the range.
   const bool lazy = s->link_owner != 0;
-  if (two_chains(s, t0, t1)) {
-    HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
-    HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
-    for (int t = t0; t < t1; ++t) {
-      launch_step(s, t, nullptr, -1, nullptr, nullptr, 0, lazy);
-      launch_step(s, t, nullptr, -1, nullptr, nullptr, 1, lazy);
-    }
-    const int rc = join_chains(s);    // the last step's link update stays pending on the joined stream (pending_links_first)
+  const int nch = chains_for(s, t0, t1);
+  if (nch > 1) {
+    if (s->link_pending >= 0 && s->link_pending != t0 - 1) pending_links_first(s);   // a stale pending update: on the whole batch, before the fork
+    int rc = fork_chains(s, nch);
+    if (rc != PEDN_OK) return rc;
+    s->run_chains = nch;
+    for (int t = t0; t < t1; ++t)
+      for (int c = 0; c < nch; ++c) launch_step(s, t, nullptr, -1, nullptr, nullptr, c, lazy);
+    s->run_chains = 1;
+    rc = join_chains(s, nch);    // the last step's link update stays pending on the joined stream (pending_links_first)
     if (rc != PEDN_OK) return rc;
   } else {
     for (int t = t0; t < t1; ++t) launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, lazy);
@@ -1370,7 +1435,7 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
 
 int pedn_plan_info(pedn_sim* s, int32_t* info, int32_t n) {
   if (!s || !info || n < 4) return fail(s, PEDN_E_ARG, "pedn_plan_info: null argument or fewer than 4 entries");
-  info[0] = s->two_streams ? 2 : 1;
+  info[0] = s->chains;
   info[1] = s->link_owner && !s->node_lp && s->v.n_pairs_corr > 0;
   info[2] = s->stream_probe_attempts;
   info[3] = (int32_t)(s->stream_probe_ms * 1000.0f + 0.5f);
@@ -1379,13 +1444,16 @@ int pedn_plan_info(pedn_sim* s, int32_t* info, int32_t n) {
 
 int pedn_set_streams(pedn_sim* s, int32_t n) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
-  if (n != 1 && n != 2) return fail(s, PEDN_E_ARG, "1 or 2 chains of launches");
-  if (n == 2 && !s->two_streams) {
+  if (n != 1 && n != 2 && n != 4) return fail(s, PEDN_E_ARG, "1, 2 or 4 chains of launches");
+  if (n > 1 && n > s->warmed_chains) {
     HIP_TRY(s, hipSetDevice(s->device));
-    int rc = warm_second_stream(s);
+    int got = 1;
+    int rc = warm_chain_streams(s, n, &got);
     if (rc != PEDN_OK) return rc;
+    s->warmed_chains = got == 3 ? 2 : got;
   }
-  s->two_streams = n == 2;
+  s->chains = n > 1 ? std::min<int>(n, std::max(s->warmed_chains, 1)) : 1;
+  s->two_streams = s->chains > 1;
   return PEDN_OK;
 }
 
@@ -1394,8 +1462,8 @@ int pedn_set_streams(pedn_sim* s, int32_t n) {
 // the first launch of the range.
 struct ProfRow { int t, chain, kind; float start, end; };
 static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows, int* chains) {
-  const bool two = two_chains(s, t0, t1);
-  const int halves = two ? 2 : 1, n = (t1 - t0) * halves;
+  const int halves = chains_for(s, t0, t1), n = (t1 - t0) * halves;
+  const bool two = halves > 1;
   const bool lazy = s->link_owner != 0;   // pedn_run's plan
   struct Events {  // destroyed on every way out of the function
     std::vector<hipEvent_t> e;
@@ -1406,8 +1474,10 @@ static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows
   for (auto& e : ev) HIP_TRY(s, hipEventCreate(&e));
   std::vector<int> tp_ran((size_t)n, 0), second((size_t)n, 0);
   if (two) {
-    HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
-    HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+    if (s->link_pending >= 0 && s->link_pending != t0 - 1) pending_links_first(s);
+    const int rc = fork_chains(s, halves);
+    if (rc != PEDN_OK) return rc;
+    s->run_chains = halves;
   }
   for (int t = t0, k = 0; t < t1; ++t)
     for (int h = 0; h < halves; ++h, ++k) {
@@ -1418,8 +1488,9 @@ static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows
     }
   const bool flushed = s->link_pending >= 0;
   for (int h = 0; h < halves; ++h) flush_links(s, two ? h : -1, &ev[(size_t)(n + h) * 6]);
+  s->run_chains = 1;
   if (two) {
-    const int rc = join_chains(s);
+    const int rc = join_chains(s, halves);
     if (rc != PEDN_OK) return rc;
   }
   HIP_TRY(s, hipGetLastError());

@@ -435,7 +435,8 @@ class Engine:
                 "stream_probe_us": int(info[3])}
 
     def set_streams(self, n):
-        """Launch plan of run() for long ranges: 1 chain of launches, or 2 (the halves of the replica batch on two streams)."""
+        """Launch plan of run() for long ranges: 1 chain of launches, or 2 / 4 (the halves / quarters of the replica batch on as many
+        streams; falls back to what the runtime's hardware queues allow -- see plan_info())."""
         self._ck(self._lib.pedn_set_streams(self._h, int(n)))
 
     # -- batched RL glue

@@ -236,6 +236,36 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
             assert np.array_equal(ref[f], got[f]), (variant, f)
 
 
+@pytest.mark.parametrize("name,steps,owner", [("melbourne", 50, "1"), ("nine_intersections", 90, "0"), ("delft", 30, "0")])
+def test_four_chain_plan_gives_identical_histories(name, steps, owner, monkeypatch):
+    """PEDN_STREAMS=4: the quarters of the batch as four chains of launches on four streams (pedn_set_streams(4)).  Whether the runtime
+    gives the four streams hardware queues of their own only decides how fast this is (the engine probes it and falls back; the probe
+    is switched off here so that the four-chain code path runs whatever the process' queues look like): same bits as one chain."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    def history(streams):
+        monkeypatch.setenv("PEDN_STREAMS", streams)
+        monkeypatch.setenv("PEDN_STREAM_PROBE", "0")
+        monkeypatch.setenv("PEDN_LINK_OWNER", owner if streams == "4" else "0")
+        np.random.seed(7)
+        net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=512, rng_seed=11)
+        e = net.engine()
+        assert e.plan_info()["chains"] == int(streams)
+        net.run(1, steps // 2)
+        net.network_loading(steps // 2)                      # a single step between two ranges
+        net.run(steps // 2 + 1, steps)
+        out = {f: e.read_block(LINK_FIELDS[f][0], 0, steps) for f in ALL_FIELDS}
+        out["tf"] = np.stack([np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 127, 128, 383, 384, 511)])
+        out["flags"] = e.error_flags()[1]
+        net.close()
+        return out
+
+    a, b = history("1"), history("4")
+    for f in a:
+        assert np.array_equal(a[f], b[f]), f
+
+
 def test_full_size_melbourne_1024_invariants():
     """BASELINE config at full size (melbourne x 1024): size-independent properties of the model
     (SURVEY section 4): cumulative = running sum of flows, pedestrian conservation, non-negativity,

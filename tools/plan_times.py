@@ -37,8 +37,9 @@ for spec in sys.argv[1:]:
         e.timer_begin()
         e.run(101, 101 + n)
         best = min(best, e.timer_end() / n * 1e3)
+    plan = e.plan_info()
     (tf, node, link), chains = e.profile_run(101 + n, 101 + n + 40)
     rc, _ = e.error_flags()
     print(f"{network:10s} x{R:5d} {lib:22s} {tag or 'default plan':28s} {best:6.2f} us/step   chains {chains}  node_kernel {node * 1e3:6.2f}  "
-          f"second launch {link * 1e3:6.2f}  stand-alone tf {tf * 1e3:5.2f}  flags {rc}", flush=True)
+          f"second launch {link * 1e3:6.2f}  stand-alone tf {tf * 1e3:5.2f}  flags {rc}  probe {plan['stream_probe_attempts']}x {plan['stream_probe_us']} us", flush=True)
     net.close()
