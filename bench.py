@@ -177,7 +177,9 @@ def live_traffic(workloads, history):
     if not os.path.exists(roc) or os.environ.get("PEDN_BENCH_CHILD"):
         return
     tmp = tempfile.mkdtemp(prefix="pedn_pmc_", dir="/tmp")
-    env = dict(os.environ, PEDN_BENCH_CHILD="1", TMPDIR="/tmp")
+    # PEDN_STREAM_PROBE=0: counter collection serialises kernels, so the probe of the two-chain plan would see no overlap and fall back
+    # to one chain -- whole-batch launches, not the half-batch ones of the timed run whose bytes these passes are meant to count
+    env = dict(os.environ, PEDN_BENCH_CHILD="1", TMPDIR="/tmp", PEDN_STREAM_PROBE="0")
     deadline = time.perf_counter() + float(os.environ.get("PEDN_BENCH_PMC_BUDGET_S", "240"))   # for ALL passes: the headline line must not wait on a slow profiler
 
     def counters(counter, tag, cmd):

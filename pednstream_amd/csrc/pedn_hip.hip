@@ -390,6 +390,7 @@ extern "C" {
 static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows, size_t row0, size_t row_stride, int replica);
 static void flush_links(pedn_sim* s, int half, hipEvent_t* ev);
 static inline void pending_links_first(pedn_sim* s);
+static void prewarm_chains(pedn_sim* s);
 
 int pedn_abi_version(void) { return PEDN_ABI_VERSION; }
 
@@ -776,7 +777,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     }
     SlotRec idle{};
     idle.node = -1;
-    std::vector<SlotRec> rec(bins.size() * 8, idle);
+    std::vector<SlotRec> rec((bins.size() + 1) * 8, idle);   // one more block of idle records behind the bins: prewarm_chains
     for (size_t b = 0; b < bins.size(); ++b) {
       int wave = 0, base = 0;
       for (int n : bins[b]) {
@@ -916,6 +917,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     TRY(warm_chain_streams(s, s->chains, &got));
     s->chains = s->warmed_chains = got == 3 ? 2 : got;
     s->two_streams = s->chains > 1;
+    if (!getenv("PEDN_NO_PREWARM")) prewarm_chains(s);
   }
 #undef TRY
   *out = s;
@@ -1271,6 +1273,29 @@ static inline void pending_links_first(pedn_sim* s) {
   if (s->link_pending >= 0) flush_links(s, -1, nullptr);
 }
 
+// The first launch of a kernel on a stream that has not run it yet costs the runtime several tens of microseconds (measured: the first
+// two-chain range of a process took 32.6-33.9 us per step over 20 steps, the following ones 29.0-29.3): pay that when the plan is
+// chosen.  Every step kernel is launched once on every chain's stream over NOTHING -- node_kernel on the block of idle slot records
+// behind the bins (its waves meet at the two barriers and leave), the link update with zero corridors.
+static void prewarm_chains(pedn_sim* s) {
+  if (s->chains < 2) return;
+  DevView v = s->v;
+  v.slot_rec = s->d_slot_rec + (size_t)s->n_blocks * 8;   // the idle block
+  DevView vl = s->v;
+  vl.n_pairs_corr = 0;
+  vl.n_trow = 0;
+  RlView q{};
+  for (int c = 0; c < s->chains; ++c) {
+    hipStream_t st = chain_stream(s, c);
+    for (int lu = 0; lu < 2; ++lu) hipLaunchKernelGGL(node_kernel_for(s, lu != 0), dim3(1, 1), dim3(512), s->node_lds, st, v, 2);
+    if (vl.hist) { hipLaunchKernelGGL((link_turn_kernel<false, false, 1, true>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
+                   hipLaunchKernelGGL((link_kernel_1r<false, true>), dim3(1), dim3(256), 0, st, vl, 1); }
+    else { hipLaunchKernelGGL((link_turn_kernel<false, false, 1, false>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
+           hipLaunchKernelGGL((link_kernel_1r<false, false>), dim3(1), dim3(256), 0, st, vl, 1); }
+  }
+  for (int c = s->chains - 1; c >= 0; --c) hipStreamSynchronize(chain_stream(s, c));
+}
+
 // lazy (owner-wave plan, pedn_run): the link update of t is left to node_kernel<LU>(t + 1) -- or to flush_links -- and this step's
 // node_kernel performs the pending one of t - 1.
 static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe = -1, bool* observed = nullptr,
@@ -1452,8 +1477,10 @@ int pedn_set_streams(pedn_sim* s, int32_t n) {
     if (rc != PEDN_OK) return rc;
     s->warmed_chains = got == 3 ? 2 : got;
   }
+  const int before = s->chains;
   s->chains = n > 1 ? std::min<int>(n, std::max(s->warmed_chains, 1)) : 1;
   s->two_streams = s->chains > 1;
+  if (s->chains > before && !getenv("PEDN_NO_PREWARM")) prewarm_chains(s);
   return PEDN_OK;
 }
 

@@ -17,6 +17,9 @@ export TMPDIR=/tmp
 
 profile() {  # $1 = suffix ("" or "_delft"), rest = bench arguments
   local SUF=$1; shift
+  # counter collection serialises kernels: without this the stream-overlap probe falls back to one chain and the passes would count
+  # whole-batch launches instead of the default plan's half-batch ones
+  export PEDN_STREAM_PROBE=0
   rm -rf $O/kt$SUF $O/pf$SUF $O/pw$SUF $O/sq1$SUF $O/sq2$SUF $O/sq3$SUF $O/sq4$SUF
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt$SUF -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra > $O/kt$SUF.log 2>&1
   echo "kernel trace$SUF done"
@@ -27,6 +30,7 @@ profile() {  # $1 = suffix ("" or "_delft"), rest = bench arguments
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/sq2$SUF -- python3 $R/bench.py "$@" --steps 48 --warmup 20 --no-cpu-baseline --no-extra > $O/sq2$SUF.log 2>&1 || echo "SQ pass 2 failed (see sq2$SUF.log)"
   rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/sq3$SUF -- python3 $R/bench.py "$@" --steps 48 --warmup 20 --no-cpu-baseline --no-extra > $O/sq3$SUF.log 2>&1 || echo "SQ pass 3 failed (see sq3$SUF.log)"
   rocprofv3 --pmc SQ_WAVES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/sq4$SUF -- python3 $R/bench.py "$@" --steps 48 --warmup 20 --no-cpu-baseline --no-extra > $O/sq4$SUF.log 2>&1 || echo "SQ pass 4 failed (see sq4$SUF.log)"
+  unset PEDN_STREAM_PROBE
   (cd $R && python3 tools/summarize_busy.py $O/sq3$SUF $O/sq4$SUF > $P/$TAG${SUF}_unit_busy.json) || true
   echo "SQ$SUF done"
   (cd $R && python3 tools/summarize_profiles.py $TAG$SUF $O/kt$SUF $O/pf$SUF $O/pw$SUF $O/cf $O/cw 20 $O/kt$SUF.log)
