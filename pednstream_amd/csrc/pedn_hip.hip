@@ -34,6 +34,8 @@ struct pedn_sim {
   int lu_waves = 8, lu_waves_pr = 6;      // the same for the instantiation that performs the link update (node_kernel<LU>)
   int link_owner = 0;  // pedn_run: node_kernel(t + 1)'s slot waves perform the link update of t (one launch per step), PEDN_LINK_OWNER
   int rl_owner = 0;    // pedn_rl_step under the owner-wave plan (PEDN_RL_OWNER)
+  int rl_chains = 0;   // pedn_rl_step steps the two halves of the envs as two chains that stay forked ACROSS calls (PEDN_RL_CHAINS)
+  int forked = 0;      // stream2 holds work of such a chain that the engine's stream does not order yet (join_forked)
   int link_pending = -1;  // owner-wave plan: step whose link update has not been performed yet, -1 none
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
   // The link update as a launch of its own runs one replica per lane (link_kernel_1r: 42-47 VGPRs, 8 waves per SIMD; melbourne x 1024
@@ -390,6 +392,7 @@ extern "C" {
 static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows, size_t row0, size_t row_stride, int replica);
 static void flush_links(pedn_sim* s, int half, hipEvent_t* ev);
 static inline void pending_links_first(pedn_sim* s);
+static inline void join_forked(pedn_sim* s);
 static void prewarm_chains(pedn_sim* s);
 
 int pedn_abi_version(void) { return PEDN_ABI_VERSION; }
@@ -844,6 +847,11 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     s->link_owner = v.n_trow == 0 && m->node_model != PEDN_NODE_OPTIMAL;
     if (const char* f = getenv("PEDN_LINK_OWNER")) s->link_owner = atoi(f) != 0;
     if (const char* f = getenv("PEDN_RL_OWNER")) s->rl_owner = atoi(f) != 0;
+    // 0 = by batch: two chains where the step is not a pure chain of latencies any more -- from 4096 envs, and from 1024 with per-env
+    // scenarios (45_intersections: 2048 envs plain 24.8-25.2 -> 24.7-25.7 us per env step, randomised 27.5-27.9 -> 25.6-26.0;
+    // 4096 envs 40.6 -> 35.9; profiles/r04_rl_chains.txt); PEDN_RL_CHAINS=1|2 forces
+    s->rl_chains = 0;
+    if (const char* f = getenv("PEDN_RL_CHAINS")) s->rl_chains = atoi(f) == 2 ? 2 : 1;
     s->node_lp = m->node_model == PEDN_NODE_OPTIMAL;
     if (s->node_lp) {  // tableau workspace: one per (regular node, replica group), sized for the largest such node
       int n_lp = 0, max_m = 0;
@@ -927,6 +935,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
 int pedn_destroy(pedn_sim* s) {
   if (!s) return PEDN_OK;
   hipSetDevice(s->device);
+  if (s->stream2) hipStreamSynchronize(s->stream2);
   if (s->stream) hipStreamSynchronize(s->stream);
   for (void* p : s->allocs) hipFree(p);
   for (pedn_sim::Stage& st : s->stage) {
@@ -951,9 +960,10 @@ int pedn_destroy(pedn_sim* s) {
 int pedn_reset(pedn_sim* s) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   HIP_TRY(s, hipSetDevice(s->device));
+  join_forked(s);
   s->tp_ready = -1;
   s->last_t = -1;
-  s->link_pending = -1;
+  s->link_pending = -1;   // discarded: the state it would complete is being cleared
   return reset_state(s);
 }
 
@@ -963,6 +973,7 @@ static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows,
   DevView& v = s->v;
   if (replica != PEDN_ALL && (replica < 0 || replica >= v.R)) return fail(s, PEDN_E_ARG, "replica out of range");
   HIP_TRY(s, hipSetDevice(s->device));
+  join_forked(s);       // every setter that goes through here (demand, turning fractions, widths) is ordered behind both chains
   pedn_sim::Stage* st;
   int rc = stage_acquire(s, (size_t)n_rows * 8, &st);
   if (rc != PEDN_OK || (rc = stage_upload(s, st, values, (size_t)n_rows * 8)) != PEDN_OK) return rc;
@@ -994,6 +1005,7 @@ int pedn_get_demand(pedn_sim* s, int32_t node, int32_t replica, double* values, 
   if (n < 0 || n > v.T1) return fail(s, PEDN_E_ARG, "more values than time indices");
   if (n == 0) return PEDN_OK;
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemcpy2D(values, 8, v.demand + (size_t)row * v.T1 * v.RS + replica, (size_t)v.RS * 8, 8, n, hipMemcpyDeviceToHost));
   return PEDN_OK;
@@ -1008,6 +1020,7 @@ int pedn_set_demand_matrix(pedn_sim* s, int32_t node, const double* values, int3
   if (n < 0 || n > v.T1) return fail(s, PEDN_E_ARG, "more demand values than time indices");
   if (n == 0) return PEDN_OK;
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   const size_t bytes = (size_t)v.R * n * 8;
   pedn_sim::Stage* st;
   int rc = stage_acquire(s, bytes, &st);
@@ -1030,6 +1043,7 @@ int pedn_set_demand_rows(pedn_sim* s, int32_t node, const int32_t* replicas, int
     if (replicas[k] < 0 || replicas[k] >= v.R) return fail(s, PEDN_E_ARG, "replica out of range");
   if (n == 0 || n_rep <= 0) return PEDN_OK;
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   // staging layout: values [n_rep][n] (f64), then the replica ids (int32)
   const size_t vbytes = (size_t)n_rep * n * 8, bytes = vbytes + (size_t)n_rep * 4;
   pedn_sim::Stage* st;
@@ -1055,6 +1069,7 @@ int pedn_draw_demand(pedn_sim* s, int32_t node, uint64_t seed, const int32_t* pa
     if (!(base[r] >= 0.0) || !(peak[r] >= 0.0) || base[r] + 2.0 * peak[r] > 500.0) return fail(s, PEDN_E_ARG, "demand rate outside [0, 500]");
   }
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   // staging layout: pattern, spike_start, spike_len (int32 [R] each, padded to 8 bytes), then base, peak, spike_height (f64 [R])
   const size_t R = (size_t)v.R, ioff = ((3 * R * 4 + 7) / 8) * 8, bytes = ioff + 3 * R * 8;
   pedn_sim::Stage* st;
@@ -1082,6 +1097,7 @@ int pedn_set_od_weights(pedn_sim* s, int32_t od, const double* values, int32_t n
   if (!s || !values) return fail(s, PEDN_E_ARG, "null argument");
   if (od < 0 || od >= s->n_od || n != s->v.T1) return fail(s, PEDN_E_ARG, "od index or length out of range");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemcpy((void*)(s->v.od_w + (size_t)od * s->v.T1), values, (size_t)n * 8, hipMemcpyHostToDevice));
   std::copy(values, values + n, s->h_od_w.begin() + (size_t)od * s->v.T1);
@@ -1111,6 +1127,7 @@ int pedn_get_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, doubl
   int a = s->node_turn_ptr[node], b = s->node_turn_ptr[node + 1];
   if (n != b - a) return fail(s, PEDN_E_ARG, "turning-fraction count does not match m(m-1)");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   const double* src = (s->h_node_dyn[node] && s->last_t >= 0) ? s->v.tfd[s->last_t & 1] : s->v.tf;
   HIP_TRY(s, hipMemcpy2D(tf, 8, src + (size_t)a * s->v.RS + replica, (size_t)s->v.RS * 8, 8, n, hipMemcpyDeviceToHost));
@@ -1198,6 +1215,7 @@ int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
   if (v.L == 0) return PEDN_OK;
   const double* src = which == PEDN_W_FRONT ? v.front : which == PEDN_W_BACK ? v.back : which == PEDN_W_SEP ? v.sepw : v.sepnp;
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemcpy2D(values, (size_t)v.R * 8, src, (size_t)v.RS * 8, (size_t)v.R * 8, v.L, hipMemcpyDeviceToHost));
   return PEDN_OK;
@@ -1269,7 +1287,18 @@ static void flush_links(pedn_sim* s, int half, hipEvent_t* ev) {
 // pedn_profile_step.  Returns 1 through *observed when the observations were part of the launch.
 // Every entry point that looks at or changes what a link update reads or writes calls this first: under the owner-wave plan the link
 // update of the last step launched may still be pending (link_pending) -- the next step's node kernel would perform it.
+static int join_chains(pedn_sim* s, int n);
+// (also: pedn_rl_step may have left the two halves of the batch stepping as two chains on two streams across calls -- `forked` -- so
+// that the engine's stream does not order stream2's work yet: joined first.  Anything that enqueues on the engine's stream or reads
+// device memory calls this, i.e. every entry point but the stepping calls themselves and the pure host getters.)
+static inline void join_forked(pedn_sim* s) {
+  if (s->forked) {
+    s->forked = 0;
+    join_chains(s, 2);
+  }
+}
 static inline void pending_links_first(pedn_sim* s) {
+  join_forked(s);
   if (s->link_pending >= 0) flush_links(s, -1, nullptr);
 }
 
@@ -1373,6 +1402,7 @@ int pedn_step(pedn_sim* s, int32_t t) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
+  join_forked(s);
   // owner-wave plan: this step's link update stays pending -- the next step's node kernel performs it, or whatever call looks at
   // or changes the state first (pending_links_first)
   launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, s->link_owner != 0);
@@ -1384,6 +1414,7 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   if (!s || !ms) return fail(s, PEDN_E_ARG, "null argument");
   if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   // hipExtLaunchKernelGGL start/stop events carry the dispatch's own begin/end timestamps (what rocprofv3 reports),
   // not the enqueue-to-completion interval an ordinary hipEventRecord bracket would measure.
   hipEvent_t ev[6];
@@ -1440,6 +1471,7 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
   // Owner-wave plan (link_owner): one launch per step for models without dynamic turning fractions -- node_kernel<LU>(t) performs the
   // link update of t - 1 -- plus one link_kernel for the last step of the range.
   const bool lazy = s->link_owner != 0;
+  join_forked(s);
   const int nch = chains_for(s, t0, t1);
   if (nch > 1) {
     if (s->link_pending >= 0 && s->link_pending != t0 - 1) pending_links_first(s);   // a stale pending update: on the whole batch, before the fork
@@ -1472,6 +1504,7 @@ int pedn_set_streams(pedn_sim* s, int32_t n) {
   if (n != 1 && n != 2 && n != 4) return fail(s, PEDN_E_ARG, "1, 2 or 4 chains of launches");
   if (n > 1 && n > s->warmed_chains) {
     HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
     int got = 1;
     int rc = warm_chain_streams(s, n, &got);
     if (rc != PEDN_OK) return rc;
@@ -1549,6 +1582,7 @@ int pedn_profile_run(pedn_sim* s, int32_t t0, int32_t t1, float ms[3], int32_t* 
   if (!s || !ms || !chains) return fail(s, PEDN_E_ARG, "null argument");
   if (t0 < 1 || t1 > s->v.T1 || t0 >= t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   std::vector<ProfRow> rows;
   int ch = 1;
   const int rc = profile_range(s, t0, t1, rows, &ch);
@@ -1565,6 +1599,7 @@ int pedn_profile_timeline(pedn_sim* s, int32_t t0, int32_t t1, float* out, int32
   if (!s || !out || !n_rows || !chains) return fail(s, PEDN_E_ARG, "null argument");
   if (t0 < 1 || t1 > s->v.T1 || t0 >= t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   std::vector<ProfRow> rows;
   int ch = 1;
   const int rc = profile_range(s, t0, t1, rows, &ch);
@@ -1718,6 +1753,7 @@ int pedn_get_link_params(pedn_sim* s, double* kc, double* kj, double* vf, int32_
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (!s->v.pr || !s->d_prm) return fail(s, PEDN_E_ARG, "no per-replica link parameters are set");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   const DevView& v = s->v;
   const size_t n = (size_t)v.L * v.R, bytes = n * (3 * 8 + 2 * 4 + 4);
   pedn_sim::Stage* st;
@@ -1744,6 +1780,7 @@ int pedn_get_link_params(pedn_sim* s, double* kc, double* kj, double* vf, int32_
 int pedn_set_od_weights_per_replica(pedn_sim* s, const double* w) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   DevView& v = s->v;
   s->tp_ready = -1;
@@ -1762,6 +1799,7 @@ int pedn_get_od_weights_per_replica(pedn_sim* s, double* w) {
   if (!s || !w) return fail(s, PEDN_E_ARG, "null argument");
   if (!s->v.pod_pr || !s->d_od_w_r) return fail(s, PEDN_E_ARG, "no per-replica OD weights are set");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   HIP_TRY(s, hipMemcpy2D(w, (size_t)s->v.R * 8, s->d_od_w_r, (size_t)s->v.RS * 8, (size_t)s->v.R * 8, s->n_od, hipMemcpyDeviceToHost));
   return PEDN_OK;
@@ -1824,6 +1862,7 @@ int pedn_rl_configure(pedn_sim* s, const pedn_rl_desc* d, int32_t* n_actions, in
   if (d->n_agents < 1) return fail(s, PEDN_E_ARG, "no agents");
   if (d->obs_mode < 1 || d->obs_mode > 5) return fail(s, PEDN_E_ARG, "obs_mode must be 1..5");
   HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);
   static const int fpl_of[6] = {0, 3, 4, 5, 2, 7};  // builders.py:47-58
   const int fpl = fpl_of[d->obs_mode];
   DevView& v = s->v;
@@ -1968,12 +2007,32 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
       }
     } else if ((rc = pedn_rl_apply_actions(s, actions, on_device)) != PEDN_OK) return rc;   // (performs a pending link update first)
   }
+  // Two chains that stay forked ACROSS calls (rl_chains): the two halves of the envs step on two streams, call after call, and are
+  // joined only when something needs the whole batch (join_forked: an observation fetch, a setter, a read, a synchronise).  A step is two
+  // dependent launches whose durations barely depend on the batch size, so the two half-batch chains run side by side almost for free
+  // (45_intersections x 2048: 25.0 -> 22.x us per env step).  Only when nothing of this call runs on the engine's stream alone: the
+  // actions are applied inside node_kernel (or there are none) and the observations ride in the second launch.
+  // (actions from the host go through the engine's own action buffer, which the other chain's previous step may still be reading)
+  const bool by_batch = s->v.RS >= 4096 || (s->v.pr && s->v.RS >= 1024);
+  const bool two = (s->rl_chains == 2 || (s->rl_chains == 0 && by_batch)) && s->warmed_chains >= 2 && s->v.RS % 256 == 0 && s->fuse_obs && (!actions || (fold != nullptr && on_device)) &&
+                   s->link_pending < 0 && !(s->v.n_trow > 0 && !s->fuse_tp);
+  if (!two) join_forked(s);
+  else if (!s->forked) {
+    if ((rc = fork_chains(s, 2)) != PEDN_OK) return rc;
+    s->forked = 1;
+  }
   for (int k = 0; k < action_gap; ++k) {
     const bool last = k == action_gap - 1;
     bool observed = false;
     // owner-wave plan of the RL step (rl_owner): only with the actions folded into node_kernel and the observations in the second launch
-    const bool lazy = s->rl_owner && s->rl_fold && s->fuse_obs && (!actions || fold != nullptr);
-    launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, -1, lazy);
+    const bool lazy = !two && s->rl_owner && s->rl_fold && s->fuse_obs && (!actions || fold != nullptr);
+    if (two) {
+      s->run_chains = 2;
+      for (int c = 0; c < 2; ++c) launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, c, false);
+      s->run_chains = 1;
+      if ((last && (obs || rewards)) || !observed) join_forked(s);
+    } else
+      launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, -1, lazy);
     HIP_TRY(s, hipGetLastError());
     if (!observed) {
       if ((rc = pedn_rl_observe(s, t + k, k > 0, last ? obs : nullptr, last ? rewards : nullptr)) != PEDN_OK) return rc;

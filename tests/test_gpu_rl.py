@@ -175,6 +175,55 @@ def _step_device_check():
         e.close()
 
 
+@pytest.mark.parametrize("randomized", [False, True])
+def test_forked_rl_chains_give_the_same_episode(randomized, monkeypatch):
+    """PEDN_RL_CHAINS=2: pedn_rl_step leaves the two halves of the envs stepping as two chains on two streams ACROSS calls and joins
+    them only when something needs the whole batch.  Against one chain: device-resident actions stepped asynchronously in stretches,
+    an observation fetch (join) after every stretch, a setter and host-side actions (which go through the engine's stream alone) in
+    between, a reset and a second episode -- observations, rewards, histories, flags identical."""
+    torch = pytest.importorskip("torch")
+    g = Golden("rl_i45_opt3")
+    B, steps = 256, 48
+
+    def episode(chains):
+        monkeypatch.setenv("PEDN_RL_CHAINS", chains)
+        monkeypatch.setenv("PEDN_STREAM_PROBE", "0")
+        np.random.seed(5)
+        env = VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", network=build_network(g, n_replicas=B, rng_seed=3))
+        e = env.network.engine()
+        gen = torch.Generator(device="cuda").manual_seed(2)
+        acts = torch.rand((steps, B, env.n_actions), generator=gen, device="cuda", dtype=torch.float64) * 4.0
+        torch.cuda.synchronize()
+        row = B * env.n_actions * 8
+        out = []
+        for ep in range(2):
+            env.reset(options={"randomize": True, "mode": "vectorised"} if randomized else None, seed=20 + ep)
+            t = 1
+            for stretch in (1, 7, 16, 5):
+                for _ in range(stretch):                              # asynchronous, nothing fetched: the chains stay forked
+                    e.rl_step_device(acts.data_ptr() + (t - 1) * row, t)
+                    t += 1
+                obs, rew = e.rl_observe(t - 1, accumulate=False)       # joins
+                out.append((obs.copy(), rew.copy()))
+                if stretch == 7:                                       # a setter between two stretches
+                    link = next(iter(env.network.links.values()))
+                    link.front_gate_width = link.front_gate_width
+                if stretch == 16:                                      # host-side actions: through the engine's own buffer and stream
+                    o, r = e.rl_step(acts[t - 1].cpu().numpy(), t, 1)
+                    out.append((o.copy(), r.copy()))
+                    t += 1
+            out.append(tuple(e.read_block(f, 0, t) for f in (0, 2, 5, 9)))
+            out.append((e.error_flags()[1],))
+        env.close()
+        return out
+
+    one, two = episode("1"), episode("2")
+    assert len(one) == len(two)
+    for a, b in zip(one, two):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
 def test_step_device_aliases_engine_buffers_and_matches_host_step():
     """In this process the engine library was loaded long before torch is imported (the earlier tests created engines):
     engine first, torch second.  Both share the one HIP runtime engine._bind_hip_runtime put in place."""
