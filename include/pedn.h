@@ -249,6 +249,13 @@ int pedn_plan_info(pedn_sim* sim, int32_t* info, int32_t n);
 
 /* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */
 int pedn_reset(pedn_sim* sim);
+/* The same for a caller that resets every episode (rl/pz_pednet_env.py:143-193 rebuilds the Network instead): in full-record mode only
+ * what a new episode reads before it writes is restored -- row 0 of every field, avg_travel_time below the moving-average window
+ * (link.py:91), the gate record (link.py:56) -- and every other row counts as unwritten until its step runs: pedn_read answers such
+ * rows with the field's initial value (what the reference's fresh arrays hold), the kernels do the same for the only reads that can
+ * land there (get_outflow's negative indices, link.py:205-212), an out-of-order step or observation clears the rows it skips first,
+ * and pedn_device_ptr clears the rest, because a zero-copy consumer may look anywhere.  Recent-history mode: the same as pedn_reset. */
+int pedn_reset_lazy(pedn_sim* sim);
 
 /* ---- per-replica scenarios on one topology (reference: NetworkEnvGenerator.create_network with
  * link_params_overrides / od_flows / demand_params_overrides, src/utils/env_loader.py:81-158, as produced by

@@ -36,6 +36,7 @@ struct pedn_sim {
   int rl_owner = 0;    // pedn_rl_step under the owner-wave plan (PEDN_RL_OWNER)
   int rl_chains = 0;   // pedn_rl_step steps the two halves of the envs as two chains that stay forked ACROSS calls (PEDN_RL_CHAINS)
   int forked = 0;      // stream2 holds work of such a chain that the engine's stream does not order yet (join_forked)
+  int valid_hi = 0x7fffffff;   // lazy reset: history rows above this index are neither written nor cleared (DevView.valid_hi)
   int link_pending = -1;  // owner-wave plan: step whose link update has not been performed yet, -1 none
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
   // The link update as a launch of its own runs one replica per lane (link_kernel_1r: 42-47 VGPRs, 8 waves per SIMD; melbourne x 1024
@@ -230,20 +231,69 @@ static int warm_chain_streams(pedn_sim* s, int want, int* got) {
   return rc;
 }
 
-static int reset_state(pedn_sim* s) {
+// rows [row0, row1) of every history field back to their initial values (`what` as in init_state_kernel; 1 = everything)
+static int clear_rows(pedn_sim* s, int row0, int row1, int what) {
   DevView& v = s->v;
-  for (int f = 0; f < 4; ++f) HIP_TRY(s, hipMemsetAsync(v.f64[f], 0, (size_t)s->rows64[f] * v.Lall * v.RS * sizeof(double), s->stream));
-  HIP_TRY(s, hipMemsetAsync(v.flags, 0, (size_t)v.RS * sizeof(uint32_t), s->stream));
+  if (row1 <= row0) return PEDN_OK;
+  if (what & 1)
+    for (int f = 0; f < 4; ++f) {
+      const int a = std::min(row0, s->rows64[f]), b = std::min(row1, s->rows64[f]);
+      if (b > a) HIP_TRY(s, hipMemsetAsync(v.f64[f] + (size_t)a * v.Lall * v.RS, 0, (size_t)(b - a) * v.Lall * v.RS * sizeof(double), s->stream));
+    }
   if (v.L > 0) {
     int max_rows = 0;  // over the fields init_state_kernel fills (all of them have L columns)
     for (int f = 4; f < 7; ++f) max_rows = std::max(max_rows, s->rows64[f]);
     for (int g = 0; g < 6; ++g) max_rows = std::max(max_rows, s->rows32[g]);
-    const size_t n_l = (size_t)max_rows * v.L * v.RS;
-    unsigned blocks = (unsigned)((n_l + 255) / 256);
-    hipLaunchKernelGGL(init_state_kernel, dim3(blocks), dim3(256), 0, s->stream, v, max_rows);
-    HIP_TRY(s, hipGetLastError());
+    const int a = std::min(row0, max_rows), b = std::min(row1, max_rows);
+    if (b > a) {
+      const size_t n_l = (size_t)(b - a) * v.L * v.RS;
+      hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0, s->stream, v, a, b - a, what);
+      HIP_TRY(s, hipGetLastError());
+    }
   }
   return PEDN_OK;
+}
+
+static int reset_state(pedn_sim* s) {
+  DevView& v = s->v;
+  HIP_TRY(s, hipMemsetAsync(v.flags, 0, (size_t)v.RS * sizeof(uint32_t), s->stream));
+  s->valid_hi = v.valid_hi = 0x7fffffff;
+  return clear_rows(s, 0, v.T1, 1);
+}
+
+// Lazy reset (full-record mode): only what a fresh episode reads before it writes is restored -- row 0 of every field, the rows of
+// avg_travel_time below the window (link.py:91: never written by the link update), the gate record (stored only where it differs from
+// the width) -- and every other row is declared unwritten (valid_hi = 0): 19.5 GB -> 2.5 GB for 45_intersections x 2048 envs.
+static int reset_state_lazy(pedn_sim* s) {
+  DevView& v = s->v;
+  if (v.hist) return reset_state(s);    // the rings are small: nothing to save
+  HIP_TRY(s, hipMemsetAsync(v.flags, 0, (size_t)v.RS * sizeof(uint32_t), s->stream));
+  int rc;
+  if ((rc = clear_rows(s, 0, 1, 1)) || (rc = clear_rows(s, 1, std::min(v.W, v.T1), 2)) || (rc = clear_rows(s, 1, v.T1, 4))) return rc;
+  s->valid_hi = v.valid_hi = 0;
+  return PEDN_OK;
+}
+
+// Rows (valid_hi, upto] cleared now: something is about to read them from memory (an out-of-order step, an observation of a step that
+// has not run, a zero-copy consumer).
+static int catch_up(pedn_sim* s, int upto) {
+  if (s->valid_hi >= upto) return PEDN_OK;
+  upto = std::min(upto, s->v.T1 - 1);
+  DevView view = s->v;
+  int rc = PEDN_OK;
+  if (upto > s->valid_hi) {
+    // everything but the gate record and the low rows of avg_travel_time, which the lazy reset restored already
+    DevView& v = s->v;
+    const int a = s->valid_hi + 1, b = upto + 1;
+    for (int f = 0; f < 4; ++f) HIP_TRY(s, hipMemsetAsync(v.f64[f] + (size_t)a * v.Lall * v.RS, 0, (size_t)(b - a) * v.Lall * v.RS * sizeof(double), s->stream));
+    if (v.L > 0) {
+      const size_t n_l = (size_t)(b - a) * v.L * v.RS;
+      hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0, s->stream, view, a, b - a, 8);
+      rc = hipGetLastError() == hipSuccess ? PEDN_OK : fail(s, PEDN_E_DEVICE, "init_state_kernel");
+    }
+    s->valid_hi = s->v.valid_hi = upto;
+  }
+  return rc;
 }
 
 static int push_uniform(pedn_sim* s) {
@@ -967,6 +1017,16 @@ int pedn_reset(pedn_sim* s) {
   return reset_state(s);
 }
 
+int pedn_reset_lazy(pedn_sim* s) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  HIP_TRY(s, hipSetDevice(s->device));
+  join_forked(s);
+  s->tp_ready = -1;
+  s->last_t = -1;
+  s->link_pending = -1;
+  return reset_state_lazy(s);
+}
+
 // values (host) -> rows of a [rows][RS] device array, one replica or all
 static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows, size_t row0, size_t row_stride, int replica) {
   if (n_rows <= 0) return PEDN_OK;
@@ -1331,6 +1391,7 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
                        const double* fold_actions = nullptr, int half = -1, bool lazy = false) {
   // half = -1: the whole batch on the engine's stream; 0 / 1: the first / second half of the replicas on stream / stream2 (the
   // caller, pedn_run, launches both halves of a step and does the per-step bookkeeping once, after the second one)
+  if (half < 0 && t - 1 > s->valid_hi) catch_up(s, t - 1);   // a step that skips ahead after a lazy reset (chains: their callers do this before the fork)
   hipStream_t stream;
   DevView v = view_of(s, half, &stream);
   lazy = lazy && !s->node_lp && v.n_pairs_corr > 0;
@@ -1392,6 +1453,7 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   else s->second_launch = 0;
   if (observed) *observed = obs_fused;
   if (last_chain(s, half)) {
+    if (s->valid_hi != 0x7fffffff && t > s->valid_hi) s->valid_hi = s->v.valid_hi = t;   // rows <= t are written once this step's launches are
     s->last_t = t;
     ++s->step_epoch;
   }
@@ -1475,6 +1537,7 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
   const int nch = chains_for(s, t0, t1);
   if (nch > 1) {
     if (s->link_pending >= 0 && s->link_pending != t0 - 1) pending_links_first(s);   // a stale pending update: on the whole batch, before the fork
+    if (t0 - 1 > s->valid_hi) catch_up(s, t0 - 1);
     int rc = fork_chains(s, nch);
     if (rc != PEDN_OK) return rc;
     s->run_chains = nch;
@@ -1535,6 +1598,7 @@ static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows
   std::vector<int> tp_ran((size_t)n, 0), second((size_t)n, 0);
   if (two) {
     if (s->link_pending >= 0 && s->link_pending != t0 - 1) pending_links_first(s);
+    if (t0 - 1 > s->valid_hi) catch_up(s, t0 - 1);
     const int rc = fork_chains(s, halves);
     if (rc != PEDN_OK) return rc;
     s->run_chains = halves;
@@ -1661,12 +1725,21 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
   int rc = stage_acquire(s, n * esz, &st);
   if (rc != PEDN_OK) return rc;
   unsigned blocks = (unsigned)((n + 255) / 256);
+  // lazy reset: rows that were neither written nor cleared since the reset read as their initial value.  sending / receiving flow of
+  // step t are entries t - 1; the gate record and avg_travel_time below the window were restored by the reset itself.
+  int hi = 0x7fffffff;
+  if (s->valid_hi != 0x7fffffff) {
+    hi = s->valid_hi;
+    if (field == F_S || field == F_R) hi = std::max(hi - 1, 0);
+    else if (field == F_GATE) hi = 0x7fffffff;
+    else if (field == 7 + G_ATT) hi = std::max(hi, v.W - 1);
+  }
   if (field < 7)
     hipLaunchKernelGGL(gather_kernel<double>, dim3(blocks), dim3(256), 0, s->stream, (const double*)v.f64[field], (double*)st->dev, t0,
-                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS, mask);
+                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS, mask, hi, (field == F_S || field == F_R) ? -1.0 : 0.0);
   else
     hipLaunchKernelGGL(gather_kernel<float>, dim3(blocks), dim3(256), 0, s->stream, (const float*)v.f32[field - 7], (float*)st->dev, t0,
-                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS, mask);
+                       t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS, mask, hi, 0.0f);
   HIP_TRY(s, hipGetLastError());
   HIP_TRY(s, hipMemcpyAsync(st->pin, st->dev, n * esz, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
@@ -1676,7 +1749,13 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
 
 void* pedn_device_ptr(pedn_sim* s, int32_t field, int64_t* columns, int64_t* replica_stride) {
   if (!s || field < 0 || field >= PEDN_N_FIELDS) return nullptr;
-  if (s->link_pending >= 0 && hipSetDevice(s->device) == hipSuccess) pending_links_first(s);   // the consumer orders itself behind pedn_stream()
+  if ((s->link_pending >= 0 || s->forked || s->valid_hi != 0x7fffffff) && hipSetDevice(s->device) == hipSuccess) {
+    pending_links_first(s);   // the consumer orders itself behind pedn_stream()
+    if (s->valid_hi != 0x7fffffff) {   // a zero-copy consumer may look at any row: finish what the lazy reset left out
+      catch_up(s, s->v.T1 - 1);
+      s->valid_hi = s->v.valid_hi = 0x7fffffff;
+    }
+  }
   if (columns) *columns = field < 4 ? s->v.Lall : s->v.L;
   if (replica_stride) *replica_stride = s->v.RS;
   return field < 7 ? (void*)s->v.f64[field] : (void*)s->v.f32[field - 7];
@@ -1974,6 +2053,7 @@ int pedn_rl_observe(pedn_sim* s, int32_t t, int32_t accumulate, float* obs, floa
   if (t < 0 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 0..T");
   HIP_TRY(s, hipSetDevice(s->device));
   pending_links_first(s);
+  if (t > s->valid_hi) catch_up(s, t);   // observations of a step that has not run read its rows as they were initialised
   DevView& v = s->v;
   RlView& q = s->rl;
   if (v.hist) hipLaunchKernelGGL(rl_observe_kernel<true>, dim3((unsigned)q.n_agents * (unsigned)(v.RS / 64)), dim3(256), 0, s->stream, v, q, t, accumulate);
@@ -2013,6 +2093,10 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
   // (45_intersections x 2048: 25.0 -> 22.x us per env step).  Only when nothing of this call runs on the engine's stream alone: the
   // actions are applied inside node_kernel (or there are none) and the observations ride in the second launch.
   // (actions from the host go through the engine's own action buffer, which the other chain's previous step may still be reading)
+  if (t - 1 > s->valid_hi) {   // skipping ahead after a lazy reset
+    join_forked(s);
+    catch_up(s, t - 1);
+  }
   const bool by_batch = s->v.RS >= 4096 || (s->v.pr && s->v.RS >= 1024);
   const bool two = (s->rl_chains == 2 || (s->rl_chains == 0 && by_batch)) && s->warmed_chains >= 2 && s->v.RS % 256 == 0 && s->fuse_obs && (!actions || (fold != nullptr && on_device)) &&
                    s->link_pending < 0 && !(s->v.n_trow > 0 && !s->fuse_tp);

@@ -126,8 +126,11 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
     double i0 = 0.0, i1 = 0.0, i2 = 0.0, i3 = 0.0;
     if (free_flow) {
       const double* in = v.f64[F_IN];
-      i0 = in[at(wrap_idx(tp - tau, T1, fl), l, v.Lall, RS, r)], i1 = in[at(wrap_idx(tp - tau - 1, T1, fl), l, v.Lall, RS, r)];
-      i2 = in[at(wrap_idx(tp - tau - 2, T1, fl), l, v.Lall, RS, r)], i3 = in[at(wrap_idx(tp - tau - 3, T1, fl), l, v.Lall, RS, r)];
+      const int w0 = wrap_idx(tp - tau, T1, fl), w1 = wrap_idx(tp - tau - 1, T1, fl), w2 = wrap_idx(tp - tau - 2, T1, fl), w3 = wrap_idx(tp - tau - 3, T1, fl);
+      i0 = in[at(w0, l, v.Lall, RS, r)], i1 = in[at(w1, l, v.Lall, RS, r)];
+      i2 = in[at(w2, l, v.Lall, RS, r)], i3 = in[at(w3, l, v.Lall, RS, r)];
+      // lazy reset: a wrapped index lands in a row of the FUTURE, which holds the last episode's value instead of the untouched 0
+      i0 = w0 > v.valid_hi ? 0.0 : i0; i1 = w1 > v.valid_hi ? 0.0 : i1; i2 = w2 > v.valid_hi ? 0.0 : i2; i3 = w3 > v.valid_hi ? 0.0 : i3;
     }
     // Philox call 0 of the sending binomial needs no data: drawn while the four loads are in flight
     uint32_t w[4] = {0u, 0u, 0u, 0u};
@@ -781,6 +784,7 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       x.co_in = rowp(v.f64[F_CO], R64(F_CO, tp), lin, Lall, RS, r0)[lane];
       x.s_prev = rowp(v.f64[F_S], R64(F_S, tm1), lin, L, RS, r0)[lane];
       x.co_sw = rowp(v.f64[F_CO], R64(F_CO, t_sw), lout, Lall, RS, r0)[lane];
+      x.co_sw = t_sw > v.valid_hi ? 0.0 : x.co_sw;   // as for ci_look below
       x.ci_out = rowp(v.f64[F_CI], R64(F_CI, tp), lout, Lall, RS, r0)[lane];
       x.r_prev = rowp(v.f64[F_R], R64(F_R, tm1), lout, L, RS, r0)[lane];
       const double fu = v.front_u[lin], bu = v.back_u[lout];
@@ -837,7 +841,9 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       int idx_s = tp + 1 - __float2int_rn(x.att_in / (float)v.dt);  // link.py:260,274
       if (idx_s < 0) idx_s = 0;
       if (idx_s > tp + 1) idx_s = tp + 1;   // a zero / negative / garbage avg_travel_time must not take the load past the rows written so far
-      const double ci_look = v.f64[F_CI][at(R64(F_CI, idx_s), lin, Lall, RS, r)];
+      double ci_look = v.f64[F_CI][at(R64(F_CI, idx_s), lin, Lall, RS, r)];
+      // (lazy reset: a zero look-back -- the PEDN_F_SAME_STEP case -- reads the row of THIS step, which an ordinary reset left at 0)
+      ci_look = idx_s > v.valid_hi ? 0.0 : ci_look;
       const double rp = recv_reverse_peds(v, Pout, lout, tp, r, x, fl);
       s_i = early ? 0.0 : send_flow<HIST>(v, Pin, lin, tp, r, x, ci_look, fl);
       PH(3, s_i);
@@ -1294,40 +1300,47 @@ __global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, uns
 }
 
 // ---- state initialisation / host <-> device helpers ---------------------------------------------------------
-__global__ void init_state_kernel(DevView v, int max_rows) {
+// rows [row0, row0 + n_rows) of the fields selected by `what` back to their initial values (bit 0: the seven f64 / six f32 link fields
+// incl. the running sum when row 0 is among them; bit 1: only avg_travel_time; bit 2: only the gate record; bit 3: everything but the
+// gate record and the rows of avg_travel_time below the window -- what a lazy reset restored already).  Rows a field does not have (a
+// shorter ring) are skipped.
+__global__ void init_state_kernel(DevView v, int row0, int n_rows, int what) {
   const int RS = v.RS, L = v.L;
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)max_rows * L * RS;
+  size_t total = (size_t)n_rows * L * RS;
   if (gid >= total) return;
   int r = (int)(gid % RS);
   int l = (int)((gid / RS) % L);
-  int t = (int)(gid / ((size_t)RS * L));  // history row (full-record mode: the time index; recent-history mode: a ring slot)
+  int t = row0 + (int)(gid / ((size_t)RS * L));  // history row (full-record mode: the time index; recent-history mode: a ring slot)
+  const size_t i = ((size_t)t * L + l) * RS + r;
   const LinkP P = v.pr ? lane_params<true>(v, v.lp[l], l, r) : v.lp[l];
   auto has64 = [&](int f) { return t <= v.m64[f]; };  // rows of a field = mask + 1 (a ring), or all of max_rows
   auto has32 = [&](int g) { return t <= v.m32[g]; };
-  if (has64(F_S)) v.f64[F_S][gid] = -1.0;
-  if (has64(F_R)) v.f64[F_R][gid] = -1.0;
-  if (has64(F_GATE)) v.f64[F_GATE][gid] = P.width;  // link.py:56
-  if (has32(G_TT)) v.f32[G_TT][gid] = t == 0 ? P.tt0 : 0.0f;
+  const bool rest = (what & 8) != 0, all = (what & 1) != 0 || rest;
+  if (all && has64(F_S)) v.f64[F_S][i] = -1.0;
+  if (all && has64(F_R)) v.f64[F_R][i] = -1.0;
+  if (((all && !rest) || (what & 4)) && has64(F_GATE)) v.f64[F_GATE][i] = P.width;  // link.py:56
+  if (all && has32(G_TT)) v.f32[G_TT][i] = t == 0 ? P.tt0 : 0.0f;
   // link.py:91: avg_travel_time[t] = travel_time[0] for t < W; the link update only writes it from t = W on, so the slots
   // of a ring (fewer rows than W) all start there
-  if (has32(G_ATT)) v.f32[G_ATT][gid] = (t < v.W || v.hist) ? P.tt0 : 0.0f;
-  if (has32(G_N)) v.f32[G_N][gid] = 0.0f;
-  if (has32(G_K)) v.f32[G_K][gid] = 0.0f;
-  if (has32(G_V)) v.f32[G_V][gid] = 0.0f;
-  if (has32(G_LF)) v.f32[G_LF][gid] = 0.0f;
-  if (t == 0) v.rsum[(size_t)l * RS + r] = P.tt0;  // link.py:84
+  if (((all && !(rest && t < v.W)) || (what & 2)) && has32(G_ATT)) v.f32[G_ATT][i] = (t < v.W || v.hist) ? P.tt0 : 0.0f;
+  if (all && has32(G_N)) v.f32[G_N][i] = 0.0f;
+  if (all && has32(G_K)) v.f32[G_K][i] = 0.0f;
+  if (all && has32(G_V)) v.f32[G_V][i] = 0.0f;
+  if (all && has32(G_LF)) v.f32[G_LF][i] = 0.0f;
+  if (all && t == 0) v.rsum[(size_t)l * RS + r] = P.tt0;  // link.py:84
 }
 
+// rows above valid_hi (lazy reset: neither written nor cleared since the reset) are answered with the field's initial value `init`
 template <typename T>
-__global__ void gather_kernel(const T* src, T* dst, int t0, int nt, int c0, int nc, int r0, int nr, int cols, int RS, int mask) {
+__global__ void gather_kernel(const T* src, T* dst, int t0, int nt, int c0, int nc, int r0, int nr, int cols, int RS, int mask, int valid_hi, T init) {
   size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)nt * nc * nr;
   if (gid >= total) return;
   int r = (int)(gid % nr);
   int c = (int)((gid / nr) % nc);
   int t = (int)(gid / ((size_t)nr * nc));
-  dst[gid] = src[((size_t)((t0 + t) & mask) * cols + (c0 + c)) * RS + (r0 + r)];
+  dst[gid] = t0 + t > valid_hi ? init : src[((size_t)((t0 + t) & mask) * cols + (c0 + c)) * RS + (r0 + r)];
 }
 
 // dst[(row0 + i) * RS + r] = src[i * src_stride + (per_replica ? r : 0)] for r in [r0, r1)

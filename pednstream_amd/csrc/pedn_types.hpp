@@ -103,6 +103,11 @@ struct DevView {
   // flow looks back an unbounded, data-dependent number of steps into them), the others are rings of mask + 1 rows.
   int32_t m64[7], m32[6];
   int32_t hist;
+  // Lazy reset (pedn_reset_lazy, full-record mode): rows above valid_hi have neither been written nor cleared since the last reset and
+  // hold the previous episode's values.  The only reads that can land there are the wrapped (negative) indices of get_outflow's
+  // look-backs (link.py:205-212: Python's inflow[-k] = the untouched tail = 0): answered with the initial value instead of the row.
+  // 0x7fffffff after an ordinary reset.
+  int32_t valid_hi;
   int32_t pairs_adj;  // 1: corridor p is the links (2p, 2p + 1) -- the reference creates the two directions of an edge one after the other --
                       // so the link update forms its row addresses from p alone, without waiting for the corridor's record
   int32_t sub0, subRS;  // replicas [sub0, sub0 + subRS) are this launch's share (the whole batch, or one half of it per stream)

@@ -150,6 +150,7 @@ def _load():
         "pedn_timer_begin": (C.c_int, [P]),
         "pedn_timer_end": (C.c_int, [P, C.POINTER(C.c_float)]),
         "pedn_reset": (C.c_int, [P]),
+        "pedn_reset_lazy": (C.c_int, [P]),
         "pedn_profile_step": (C.c_int, [P, C.c_int32, C.POINTER(C.c_float)]),
         "pedn_profile_run": (C.c_int, [P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
         "pedn_profile_timeline": (C.c_int, [P, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -191,7 +192,7 @@ def lib():
 EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy", "pedn_set_demand", "pedn_set_demand_matrix", "pedn_set_demand_rows", "pedn_get_demand", "pedn_draw_demand",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
-           "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_plan_info", "pedn_rl_configure",
+           "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_reset_lazy", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_plan_info", "pedn_rl_configure",
            "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
            "pedn_set_od_weights_per_replica", "pedn_get_od_weights_per_replica", "pedn_get_link_params", "pedn_randomize_scenarios", "pedn_reset_widths"]
 
@@ -378,8 +379,11 @@ class Engine:
     def synchronize(self):
         self._ck(self._lib.pedn_synchronize(self._h))
 
-    def reset(self):
-        self._ck(self._lib.pedn_reset(self._h))
+    def reset(self, lazy=False):
+        """Back to t = 0.  lazy: only what a new episode reads before it writes is restored (pedn_reset_lazy); rows of steps that have
+        not run yet read as their initial values through read_block / read_column, but a zero-copy consumer (device_ptr) makes the
+        engine clear them after all."""
+        self._ck(self._lib.pedn_reset_lazy(self._h) if lazy else self._lib.pedn_reset(self._h))
 
     def error_flags(self):
         flags = np.zeros(self.n_replicas, dtype=np.uint32)

@@ -553,10 +553,11 @@ class Network:
         self._epoch += 1
         self._col_cache.clear()
 
-    def reset(self):
+    def reset(self, lazy=False):
         """Back to t = 0 in place (the reference rebuilds the Network instead, rl/pz_pednet_env.py:163-168): histories cleared
-        on the device, ``current_step`` 0, no cached column survives."""
-        self._flush().reset()
+        on the device, ``current_step`` 0, no cached column survives.  ``lazy``: see ``Engine.reset`` (the batched RL env resets
+        this way: 2.9 -> 0.4 ms for 19.5 GB of histories)."""
+        self._flush().reset(lazy=lazy)
         self.current_step = 0
         self._invalidate()
 

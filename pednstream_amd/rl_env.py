@@ -232,7 +232,7 @@ class VecPedNetEnv:
         eng = net.engine()
         if options and options.get("randomize", False):
             self.randomize(seed, mode=options.get("mode", "reference"))
-        net.reset()
+        net.reset(lazy=True)
         net._init_dynamic_host_state()
         init = net._widths          # every env starts from the same widths: broadcast on the device instead of four [L, R] uploads
         eng.reset_widths(init["front"][:, 0], init["back"][:, 0], init["sep"][:, 0])

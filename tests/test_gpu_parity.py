@@ -266,6 +266,68 @@ def test_four_chain_plan_gives_identical_histories(name, steps, owner, monkeypat
         assert np.array_equal(a[f], b[f]), f
 
 
+@pytest.mark.parametrize("name,steps1,steps2", [("nine_intersections", 260, 90), ("long_corridor", 200, 70), ("melbourne", 120, 40), ("delft", 60, 25)])
+def test_lazy_reset_serves_a_second_episode_like_a_fresh_engine(name, steps1, steps2):
+    """pedn_reset_lazy restores only what a new episode reads before it writes and declares every other row unwritten.  A second,
+    DIFFERENT and shorter episode on the same engine must equal that episode on a fresh engine in every row of every field -- the rows
+    behind its last step included, which still hold the first episode's values in memory: reads answer them with the initial values,
+    get_outflow's wrapped look-backs likewise (nine_intersections: jammed links look back further than the episode is old).  Then a
+    step that skips ahead, and a zero-copy consumer (device_ptr), after which the rows are really clear."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    def build():
+        np.random.seed(7)
+        return NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=64, rng_seed=11)
+
+    def demand(net, key, scale):
+        T = net.simulation_steps
+        for nid in net.origin_nodes:
+            rows = np.stack([np.random.default_rng(key + 7 * r + 1000 * int(nid)).poisson(scale, T).astype(np.float64) for r in range(64)])
+            net.set_demand_matrix(nid, rows)
+
+    def everything(net, upto):
+        e = net.engine()
+        out = {f: e.read_block(LINK_FIELDS[f][0], 0, upto) for f in ALL_FIELDS}
+        out["flags"] = e.error_flags()[1]
+        return out
+
+    a = build()
+    T = a.simulation_steps
+    demand(a, 1, 30.0)
+    a.run(1, steps1, check=False)                                   # episode 1: busy, long
+    a.reset(lazy=True)
+    demand(a, 2, 6.0)
+    a.run(1, steps2, check=False)                                   # episode 2: another demand, shorter
+    b = build()
+    demand(b, 2, 6.0)
+    b.run(1, steps2, check=False)
+    got, want = everything(a, T + 1), everything(b, T + 1)
+    for f in want:
+        assert np.array_equal(got[f], want[f]), f
+    # skipping ahead after a lazy reset: the rows in between are cleared first
+    a.reset(lazy=True)
+    b.reset()
+    for net in (a, b):
+        net.engine().step(steps2 + 3)
+        net.engine().step(steps2 + 4)
+    got, want = everything(a, T + 1), everything(b, T + 1)
+    for f in want:
+        assert np.array_equal(got[f], want[f]), f
+    # a zero-copy consumer: the engine finishes the clear, the rows are physically what a fresh engine holds
+    a.reset(lazy=True)
+    a.run(1, 12, check=False)
+    e = a.engine()
+    assert e.device_ptr(LINK_FIELDS["inflow"][0])
+    b.reset()
+    b.run(1, 12, check=False)
+    got, want = everything(a, T + 1), everything(b, T + 1)
+    for f in want:
+        assert np.array_equal(got[f], want[f]), f
+    a.close()
+    b.close()
+
+
 def test_full_size_melbourne_1024_invariants():
     """BASELINE config at full size (melbourne x 1024): size-independent properties of the model
     (SURVEY section 4): cumulative = running sum of flows, pedestrian conservation, non-negativity,
