@@ -418,7 +418,7 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
         left = n
         while left > 0:
             if state["t"] >= T:
-                e.reset()
+                e.reset(lazy=True)      # an episode turn-over inside the timed region: what a new episode reads before it writes is restored
                 state["t"] = 1
             k = min(left, T - state["t"])
             e.run(state["t"], state["t"] + k)
