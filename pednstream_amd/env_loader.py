@@ -203,20 +203,28 @@ class NetworkEnvGenerator:
     def generate_random_link_params(self, seed: int = None) -> dict:
         if seed is not None:
             np.random.seed(seed)
-        corridors = []
-        ed = self.network_data.get("edge_distances") if self.network_data else None
-        if ed:
-            corridors = [f"{u}_{v}" for (u, v) in ed.keys() if u < v]
-        elif self.network_data and "adjacency_matrix" in self.network_data:
-            rows, cols = np.where(self.network_data["adjacency_matrix"] == 1)
-            corridors = [f"{u}_{v}" for u, v in zip(rows, cols) if u < v]
+        # the corridor list depends on the scenario's topology only: built once per loaded network (the batched env calls this once
+        # per env and reset).  np.random.choice(list, k, replace=False) draws permutation(len(list))[:k] whatever the elements are, so
+        # choosing INDICES consumes the same random numbers as the reference's choice over the strings
+        cache = getattr(self, "_corridor_cache", None)
+        if cache is None or cache[0] is not self.network_data:
+            corridors = []
+            ed = self.network_data.get("edge_distances") if self.network_data else None
+            if ed:
+                corridors = [f"{u}_{v}" for (u, v) in ed.keys() if u < v]
+            elif self.network_data and "adjacency_matrix" in self.network_data:
+                rows, cols = np.where(self.network_data["adjacency_matrix"] == 1)
+                corridors = [f"{u}_{v}" for u, v in zip(rows, cols) if u < v]
+            cache = self._corridor_cache = (self.network_data, corridors)
+        corridors = cache[1]
         params = self.config["params"]
         defaults = params["default_link"]
         out = {}
         if corridors:
             k = int(len(corridors) * 0.2)
             if k > 0:
-                for link_id in np.random.choice(corridors, k, replace=False):
+                for idx in np.random.choice(len(corridors), k, replace=False):
+                    link_id = corridors[idx]
                     cur = params["links"].get(link_id, {})
                     ov = {}
                     if np.random.random() < 0.5:

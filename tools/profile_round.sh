@@ -84,6 +84,7 @@ if [ "$PART" = all ] || [ "$PART" = bench ]; then
   { python3 bench.py --network nine_intersections --replicas 256 --no-cpu-baseline --no-extra; python3 bench.py --network 45_intersections --replicas 2048 --no-cpu-baseline --no-extra; } > $P/${TAG}_small_configs.jsonl 2>> $O/bench.err
 fi
 if [ "$PART" = all ] || [ "$PART" = extras ]; then
+  make -s -C pednstream_amd/csrc phase-profile 2>> $O/bench.err || true      # the instrumented build must match the engine's ABI
   python3 tools/phase_profile.py melbourne delft 45_intersections:2048 nine_intersections:256 > $P/${TAG}_phase_profile.txt 2>> $O/bench.err
   PEDN_FUSE_TP=0 python3 tools/turn_phase_profile.py delft >> $P/${TAG}_phase_profile.txt 2>> $O/bench.err
   python3 tools/turn_phase_profile.py delft | sed 's/^== /== (inside link_turn_kernel) /' >> $P/${TAG}_phase_profile.txt 2>> $O/bench.err
