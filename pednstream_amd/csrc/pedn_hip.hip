@@ -52,7 +52,7 @@ struct pedn_sim {
   int warmed_chains = 1;  // chains whose streams exist and were probed to overlap
   int chains = 1;         // plan of pedn_run for long ranges: 1, 2 or 4 chains of launches (two_streams = chains > 1)
   int run_chains = 1;     // chains of the range being launched (launch_step / flush_links: the last chain does the bookkeeping)
-  int streams_probed = 0, stream_probe_attempts = 0;   // warm_second_stream: stream2 was checked to overlap with stream
+  int stream_probe_attempts = 0;   // warm_chain_streams: probes run until the chains' streams were seen to overlap
   float stream_probe_ms = 0.0f;
   int two_streams = 0;    // pedn_run launches the two halves of the batch on two streams (replicas are independent)
   int second_launch = 0;  // launch_step: a launch followed node_kernel
