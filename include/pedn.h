@@ -316,7 +316,9 @@ int pedn_rl_observe(pedn_sim* sim, int32_t t, int32_t accumulate, float* obs, fl
 /* apply -> action_gap x (pedn_step(t+k), observe) in one call (pz_pednet_env.py:195-254).  obs / rewards NULL: asynchronous, the
  * results stay in the device buffers (pedn_rl_device_ptr), complete after pedn_synchronize.  With on_device actions and nothing
  * fetched, large batches step as two chains on two streams that stay forked across calls (the halves of the envs are independent);
- * every call that needs the whole batch joins them first, so callers see the same ordering as on one stream. */
+ * every call that needs the whole batch joins them first, so callers see the same ordering as on one stream.  on_device = 2: device
+ * actions as with 1, and every launch of the call goes to pedn_stream() -- for a caller that orders the call between its own streams
+ * and the engine's with events instead of host synchronisation (VecPedNetEnv.step_device(sync=False)). */
 int pedn_rl_step(pedn_sim* sim, const double* actions, int32_t on_device, int32_t t, int32_t action_gap, float* obs,
                  float* rewards);
 /* device buffers for zero-copy consumers: 0 actions (f64 [R][n_actions]), 1 observations (f32 [R][n_obs]), 2 rewards (f32 [R][n_agents]) */

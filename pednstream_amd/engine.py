@@ -471,8 +471,13 @@ class Engine:
         self._ck(self._lib.pedn_rl_observe(self._h, int(t), int(accumulate), obs.ctypes.data_as(C.c_void_p), rew.ctypes.data_as(C.c_void_p)))
         return obs, rew
 
-    def rl_step(self, actions, t, action_gap=1, fetch=True):
-        """apply -> action_gap x (step, observe); returns host copies of the last observations and the summed rewards."""
+    def rl_step(self, actions, t, action_gap=1, fetch=True, ordered=False):
+        """apply -> action_gap x (step, observe); returns host copies of the last observations and the summed rewards.
+        ordered (only without actions and without a fetch): every launch on ``stream_ptr()``, see rl_step_device."""
+        if ordered:
+            assert actions is None and not fetch
+            self._ck(self._lib.pedn_rl_step(self._h, None, 2, int(t), int(action_gap), None, None))
+            return None, None
         a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float64)
         if a is not None:
             assert a.shape == (self.n_replicas, self.rl_n_actions), a.shape
@@ -485,10 +490,15 @@ class Engine:
                                         None if rew is None else rew.ctypes.data_as(C.c_void_p)))
         return obs, rew
 
-    def rl_step_device(self, actions_ptr, t, action_gap=1):
+    def rl_step_device(self, actions_ptr, t, action_gap=1, ordered=False):
         """Same as rl_step with the action rows already resident in HBM (raw device pointer, e.g. torch ``data_ptr()``);
-        observations and rewards stay in the device buffers (``rl_device_ptr``)."""
-        self._ck(self._lib.pedn_rl_step(self._h, C.c_void_p(int(actions_ptr)), 1, int(t), int(action_gap), None, None))
+        observations and rewards stay in the device buffers (``rl_device_ptr``).  ordered: every launch on ``stream_ptr()`` (for a
+        caller that chains the call to its own streams with events)."""
+        self._ck(self._lib.pedn_rl_step(self._h, C.c_void_p(int(actions_ptr)), 2 if ordered else 1, int(t), int(action_gap), None, None))
+
+    def stream_ptr(self):
+        """hipStream_t of the engine (``pedn_stream``), e.g. for ``torch.cuda.ExternalStream``."""
+        return int(self._lib.pedn_stream(self._h) or 0)
 
     def rl_device_ptr(self, which):
         return self._lib.pedn_rl_device_ptr(self._h, int(which))

@@ -152,6 +152,7 @@ class VecPedNetEnv:
                                                                     history=history)
         self.simulation_steps = self.network.params["simulation_steps"]
         self.scenarios = None          # the ScenarioBatch of the last randomised reset
+        self._ext_stream = None        # torch view of the engine's stream (step_device(sync=False))
         ut = self.network.params["unit_time"]
         self._max_delta_sep_width = 0.25 * ut          # pz_pednet_env.py:84-86
         self._max_delta_gate_width = 0.25 * ut
@@ -252,12 +253,17 @@ class VecPedNetEnv:
         terminated = (self.sim_step - 1) >= self.simulation_steps     # pz_pednet_env.py:592 evaluated before the increment
         return obs, rew, terminated, False, {}
 
-    def step_device(self, actions):
+    def step_device(self, actions, sync=True):
         """``step`` for an on-GPU learner: ``actions`` is a torch CUDA tensor (float64, [n_envs, n_actions], contiguous) or None;
         returns ``(obs, rewards, terminated)`` where obs [n_envs, n_obs] and rewards [n_envs, n_agents] are float32 torch tensors
         that ALIAS the engine's device buffers (``pedn_rl_device_ptr``) -- no host copy.  They are overwritten by the next
         step, so clone what must be kept.  The call waits for the caller's current torch stream before launching and for the
         engine's stream before returning, so plain sequential use is safe.
+
+        ``sync=False``: no host synchronisation at all -- the engine's stream waits (on the device) for the caller's current torch
+        stream, and that stream then waits for the engine's: the policy's kernels, the env step and whatever consumes the observations
+        are chained by events, and the host runs ahead enqueueing the next step (45_intersections x 2048 envs with a random torch
+        policy: 1.4e7 -> 3e7+ env-steps/s end to end).  Work issued on OTHER torch streams must be ordered by the caller.
 
         torch and the engine share one HIP runtime whichever is imported first (``engine._bind_hip_runtime``)."""
         import torch
@@ -270,13 +276,26 @@ class VecPedNetEnv:
             if not (actions.is_cuda and actions.dtype == torch.float64 and actions.is_contiguous()
                     and tuple(actions.shape) == (self.n_envs, self.n_actions)):
                 raise ValueError(f"actions must be a contiguous float64 CUDA tensor of shape {(self.n_envs, self.n_actions)}")
-            torch.cuda.current_stream(actions.device).synchronize()
             ptr = actions.data_ptr()
-        if ptr:
-            eng.rl_step_device(ptr, self.sim_step, self.action_gap)
+        if not sync:
+            dev = torch.device("cuda", self.network.device)
+            if self._ext_stream is None:
+                self._ext_stream = torch.cuda.ExternalStream(eng.stream_ptr(), device=dev)
+            cur = torch.cuda.current_stream(dev)
+            self._ext_stream.wait_stream(cur)                       # the actions are ready when the engine's launches start
+            if ptr:
+                eng.rl_step_device(ptr, self.sim_step, self.action_gap, ordered=True)
+            else:
+                eng.rl_step(None, self.sim_step, self.action_gap, fetch=False, ordered=True)
+            cur.wait_stream(self._ext_stream)                       # whatever the caller enqueues next sees this step's results
         else:
-            eng.rl_step(None, self.sim_step, self.action_gap, fetch=False)
-        eng.synchronize()
+            if actions is not None:
+                torch.cuda.current_stream(actions.device).synchronize()
+            if ptr:
+                eng.rl_step_device(ptr, self.sim_step, self.action_gap)
+            else:
+                eng.rl_step(None, self.sim_step, self.action_gap, fetch=False)
+            eng.synchronize()
         self.sim_step += self.action_gap
         self.network.current_step = self.sim_step - 1
         self.network._widths_stale = True

@@ -224,6 +224,37 @@ def test_forked_rl_chains_give_the_same_episode(randomized, monkeypatch):
             assert np.array_equal(x, y)
 
 
+def test_step_device_without_host_synchronisation_gives_the_same_rollout():
+    """step_device(sync=False): the engine's stream waits for the caller's torch stream and vice versa through events only.  A rollout
+    whose actions depend on the previous observations (so that any missing dependency would show) equals the synchronous one."""
+    torch = pytest.importorskip("torch")
+    g = Golden("rl_i45_opt3")
+    B, steps = 128, 40
+
+    def rollout(sync):
+        env = VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", network=build_network(g, n_replicas=B, rng_seed=3))
+        env.reset()
+        gen = torch.Generator(device="cuda").manual_seed(1)
+        obs = torch.zeros((B, env.n_obs), device="cuda")
+        total = torch.zeros(B, device="cuda", dtype=torch.float64)
+        trace = []
+        for _ in range(steps):
+            noise = torch.rand((B, env.n_actions), generator=gen, device="cuda", dtype=torch.float64)
+            feedback = (obs[:, :env.n_actions].double().abs() % 1.0)           # the policy reads the last observations
+            actions = (4.0 * (0.5 * noise + 0.5 * feedback)).contiguous()
+            obs, rew, _ = env.step_device(actions, sync=sync)
+            total += rew[:, 0].double()
+            trace.append(obs.clone())
+        torch.cuda.synchronize()
+        out = (torch.stack(trace).cpu().numpy(), total.cpu().numpy(), env.network.engine().read_block(0, 0, steps))
+        env.close()
+        return out
+
+    a, b = rollout(True), rollout(False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 def test_step_device_aliases_engine_buffers_and_matches_host_step():
     """In this process the engine library was loaded long before torch is imported (the earlier tests created engines):
     engine first, torch second.  Both share the one HIP runtime engine._bind_hip_runtime put in place."""
