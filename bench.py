@@ -359,6 +359,35 @@ def sustained_rl(network, B, history, mode, episodes=3):
             "history": history, "reset": mode}
 
 
+def rl_end_to_end(network, B, steps=300):
+    """Config #5 with a policy in the loop: a random torch policy on the GPU whose actions depend on nothing but torch's generator, the
+    observations / rewards consumed by torch ops -- env-steps/s END TO END (host enqueue included), with step_device synchronising
+    the host every step and with the streams chained by events (sync=False)."""
+    import torch
+
+    from pednstream_amd.rl_env import VecPedNetEnv
+
+    env = VecPedNetEnv(network, n_envs=B, obs_mode="option3", action_gap=1, seed=0, data_dir=os.path.join(ROOT, "data"), history="recent")
+    low = torch.as_tensor(env.action_low, device="cuda", dtype=torch.float64)
+    span = torch.as_tensor(env.action_high, device="cuda", dtype=torch.float64) - low
+    out = {}
+    for label, sync in (("host_synchronised_every_step", True), ("streams_chained_by_events", False)):
+        env.reset()
+        gen = torch.Generator(device="cuda").manual_seed(0)
+        ret = torch.zeros(B, device="cuda")
+        K = min(steps, env.simulation_steps - 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            actions = low + span * torch.rand((B, env.n_actions), generator=gen, device="cuda", dtype=torch.float64)
+            obs, rew, _ = env.step_device(actions, sync=sync)
+            ret += rew[:, 0]
+        torch.cuda.synchronize()
+        out[label] = {"value": B * K / (time.perf_counter() - t0), "unit": "env-steps/s", "steps": K, "mean_return": float(ret.mean())}
+    env.close()
+    return out
+
+
 def bench_rl(args):
     print(json.dumps(measure_rl(args.network, args.replicas, args.steps, args.warmup, args.history, args.randomize)), flush=True)
 
@@ -710,6 +739,8 @@ def main():
             "by_n_envs_recent_history": {str(n): {k: v for k, v in measure_rl("45_intersections", n, args.steps, args.warmup, "recent", randomized=False).items()
                                                   if k in ("value", "unit", "device_ms_per_step", "whole_step_frac", "steps")}
                                          for n in (2048, 4096, 8192)},
+            # a policy in the loop (torch on the same GPU): what a rollout sees end to end
+            "end_to_end_random_torch_policy": rl_end_to_end("45_intersections", 2048),
             # whole episodes WITH their resets (rl/pz_pednet_env.py:143-193 resets every episode)
             "sustained": {f"{mode}_{hist}": sustained_rl("45_intersections", 2048, hist, mode)
                           for hist in ("full", "recent") for mode in ("plain", "vectorised", "reference")}})
