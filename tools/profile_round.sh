@@ -43,6 +43,11 @@ if [ "$PART" = all ] || [ "$PART" = trace ]; then
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/cf -- python3 $R/tools/pmc_calibrate.py > $O/cf.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/cw -- python3 $R/tools/pmc_calibrate.py > $O/cw.log 2>&1
   profile "" --network melbourne
+  # the same command with ONE chain of launches (PEDN_STREAMS=1): every launch covers the whole batch and runs alone -- the per-launch
+  # figure a reader can check by hand (bytes of the whole batch / mean launch duration)
+  rm -rf $O/kt1
+  PEDN_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt1 -- python3 $R/bench.py --network melbourne --no-cpu-baseline --no-extra --no-live-traffic > $O/kt1.log 2>&1
+  cp $O/kt1/*/*_kernel_stats.csv $P/${TAG}_one_chain_kernel_stats.csv
   profile _delft --network delft
   # config #5: per-kernel durations of the batched RL step, plain and after reset(options={'randomize': True})
   rm -rf $O/ktrl $O/ktrl2
