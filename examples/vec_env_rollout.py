@@ -41,6 +41,9 @@ def main():
     low = torch.as_tensor(env.action_low, device="cuda", dtype=torch.float64)
     span = torch.as_tensor(env.action_high, device="cuda", dtype=torch.float64) - low
     ret_d = torch.zeros(n_envs, device="cuda")
+    for _ in range(20):                                   # torch's first-use initialisation is not part of either rate below
+        (low + span * torch.rand((n_envs, env.n_actions), generator=gen, device="cuda", dtype=torch.float64)).sum()
+    gen.manual_seed(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
