@@ -106,8 +106,9 @@ class ScenarioBatch:
 
     def _link_overrides(self, r, overrides):
         net = self.net
+        A = {k: self._matrix(k) for k in self._base}     # the [L, R] matrices once per call (they are properties: fetched lazily)
         for k, col in self._base.items():        # the scenario of replica r starts from the base configuration
-            getattr(self, k)[:, r] = col
+            A[k][:, r] = col
         pairs = {_pair_of(link_id) for link_id in overrides}
         edges = {}
         for pr in pairs:
@@ -132,8 +133,8 @@ class ScenarioBatch:
                 vf, kc, kj = lp["free_flow_speed"], lp["k_critical"], lp["k_jam"]
                 tt0, fft, tsw = derive_statics(link.length, vf, kc, kj, net.unit_time)
                 k = link.index
-                self.kc[k, r], self.kj[k, r], self.vf[k, r] = kc, kj, vf
-                self.fft[k, r], self.tau_sw[k, r], self.tt0[k, r] = fft, tsw, tt0
+                A["kc"][k, r], A["kj"][k, r], A["vf"][k, r] = kc, kj, vf
+                A["fft"][k, r], A["tau_sw"][k, r], A["tt0"][k, r] = fft, tsw, tt0
 
     def set_replica(self, r, link_params_overrides=None, od_flows=None, demand=None, demand_params_overrides=None):
         """Scenario of replica ``r`` in the vocabulary of ``create_network``.  ``demand`` maps node id -> array and wins over
