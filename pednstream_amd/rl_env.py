@@ -153,6 +153,7 @@ class VecPedNetEnv:
         self.simulation_steps = self.network.params["simulation_steps"]
         self.scenarios = None          # the ScenarioBatch of the last randomised reset
         self._ext_stream = None        # torch view of the engine's stream (step_device(sync=False))
+        self._init_widths = None       # [L, 3] initial front / back / separator widths (reset)
         ut = self.network.params["unit_time"]
         self._max_delta_sep_width = 0.25 * ut          # pz_pednet_env.py:84-86
         self._max_delta_gate_width = 0.25 * ut
@@ -234,9 +235,14 @@ class VecPedNetEnv:
         if options and options.get("randomize", False):
             self.randomize(seed, mode=options.get("mode", "reference"))
         net.reset(lazy=True)
-        net._init_dynamic_host_state()
-        init = net._widths          # every env starts from the same widths: broadcast on the device instead of four [L, R] uploads
-        eng.reset_widths(init["front"][:, 0], init["back"][:, 0], init["sep"][:, 0])
+        # every env starts from the same widths: broadcast on the device instead of four [L, R] uploads; the host mirrors (four [L, R]
+        # arrays, 11 MB at 2048 envs) are not rebuilt -- they are marked stale and come back from the device if somebody looks
+        if self._init_widths is None:
+            self._init_widths = np.array([l._init_widths for l in net._link_list], dtype=np.float64).reshape(net.n_links, 3)
+        init = self._init_widths
+        eng.reset_widths(init[:, 0].copy(), init[:, 1].copy(), init[:, 2].copy())
+        net._widths_stale = True
+        net._tf_host = {}
         self.sim_step = 1
         obs, _ = eng.rl_observe(self.sim_step, accumulate=False)
         return obs, {}
