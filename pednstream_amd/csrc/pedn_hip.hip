@@ -34,6 +34,13 @@ struct pedn_sim {
   int lu_waves = 8, lu_waves_pr = 6;      // the same for the instantiation that performs the link update (node_kernel<LU>)
   int link_owner = 0;  // pedn_run: node_kernel(t + 1)'s slot waves perform the link update of t (one launch per step), PEDN_LINK_OWNER
   int rl_owner = 0;    // pedn_rl_step under the owner-wave plan (PEDN_RL_OWNER)
+  // Single-launch plan of small batches with dynamic turning fractions (inline_tf): every device-computed row is short enough for ONE
+  // wave and its probabilities fit PEDN_TF_INL_ROWS LDS rows (inline_tf_ok), and the whole node_kernel grid is one generation at 4 waves
+  // per SIMD: the slot waves of node_kernel<LU, TF> compute their own rows, a step is one launch.
+  bool inline_tf_ok = false;
+  int inline_tf = 0;
+  size_t node_lds_tf = 0;   // dynamic LDS of node_kernel<.., TF>
+  std::vector<int32_t> h_slot_trow;
   int rl_chains = 0;   // pedn_rl_step steps the two halves of the envs as two chains that stay forked ACROSS calls (PEDN_RL_CHAINS)
   int forked = 0;      // stream2 holds work of such a chain that the engine's stream does not order yet (join_forked)
   int valid_hi = 0x7fffffff;   // lazy reset: history rows above this index are neither written nor cleared (DevView.valid_hi)
@@ -443,6 +450,8 @@ static int push_rows(pedn_sim* s, double* dst, const double* values, int n_rows,
 static void flush_links(pedn_sim* s, int half, hipEvent_t* ev);
 static inline void pending_links_first(pedn_sim* s);
 static inline void join_forked(pedn_sim* s);
+typedef void (*node_kernel_fn)(DevView, int);
+static node_kernel_fn node_kernel_for(const pedn_sim* s, bool lu, bool tf);
 static void prewarm_chains(pedn_sim* s);
 
 int pedn_abi_version(void) { return PEDN_ABI_VERSION; }
@@ -680,6 +689,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         for (; cnt < 4; ++cnt) { packed.push_back(Row{-1, 0, 0, 0, 0}); lds_base.push_back(0); }
       }
     }
+    s->h_slot_trow.assign(n_slots, -1);
+    s->inline_tf_ok = !packed.empty();
     std::vector<int32_t> rwords(std::max<size_t>(packed.size(), 1) * PEDN_TROW_WORDS, 0), gwords;
     std::vector<int32_t> prow(std::max(m->n_pair, 1), -1);  // product -> where its probability is, -1: the constant 1
     int n_over = 0, n_multi = 0;  // n_over: rows of ent_p, for probabilities beyond a workgroup's LDS rows
@@ -743,6 +754,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         if (slot >= 0 && E[2]) any_sep = 1;
       }
       w[3] = n_g; w[6] = (int)used.size(); w[7] = any_sep; w[107] = over; w[108] = packed[ri].groups > coop_groups;
+      w[109] = lds_base[ri];
+      s->h_slot_trow[s0 + i] = (int)ri;
+      if (over || packed[ri].groups > coop_groups || lds_rows > PEDN_TF_INL_ROWS) s->inline_tf_ok = false;
     }
     gwords.resize(gwords.size() + 8 * 32, 0);  // turn_frac_body reads a chunk of four records ahead; padding has n = 0
     rows = packed;
@@ -830,6 +844,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     }
     SlotRec idle{};
     idle.node = -1;
+    idle.trow = -1;
     std::vector<SlotRec> rec((bins.size() + 1) * 8, idle);   // one more block of idle records behind the bins: prewarm_chains
     for (size_t b = 0; b < bins.size(); ++b) {
       int wave = 0, base = 0;
@@ -839,6 +854,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
           SlotRec& R = rec[b * 8 + wave++];
           R.node = n; R.slot = k; R.base = base; R.m = d;
           R.kind = m->node_kind[n]; R.dyn = s->h_slot_dyn[m->node_slot_ptr[n] + k];
+          R.trow = s->h_slot_trow.empty() ? -1 : s->h_slot_trow[m->node_slot_ptr[n] + k];
           R.lin = m->slot_in_link[m->node_slot_ptr[n] + k];
           R.lout = m->slot_out_link[m->node_slot_ptr[n] + k];
           R.turn0 = m->node_turn_ptr[n];
@@ -896,6 +912,26 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // link-update workgroups that leave it save (delft x 1024: 42.1-42.6 -> 44.2).  PEDN_LINK_OWNER=0|1 overrides.
     s->link_owner = v.n_trow == 0 && m->node_model != PEDN_NODE_OPTIMAL;
     if (const char* f = getenv("PEDN_LINK_OWNER")) s->link_owner = atoi(f) != 0;
+    // Single-launch plan with dynamic turning fractions: the rows computed inside node_kernel<LU, TF> by the slot waves themselves.  That
+    // instantiation is built for 2 waves per SIMD (1 block per CU): only where the whole grid is one generation of them -- small
+    // batches, which are chains of latencies and gain a whole launch (nine_intersections x 256: 17.2 -> ... us per step).
+    s->node_lds_tf = s->node_lds + (size_t)8 * PEDN_TF_INL_LDS * sizeof(double);
+    v.tf_lds_off = (int32_t)(s->node_lds / sizeof(double));
+    bool inl_possible = s->inline_tf_ok && m->node_model != PEDN_NODE_OPTIMAL && s->node_lds_tf <= 160 * 1024;
+    if (inl_possible && s->node_lds_tf > 64 * 1024) {   // more dynamic LDS than a kernel gets by default: ask for it (gfx950: 160 KB per CU)
+      for (int pr = 0; pr < 2 && inl_possible; ++pr) {
+        DevView& vv = s->v;
+        const int keep = vv.pr;
+        vv.pr = pr;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel_for(s, true, true)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->node_lds_tf) != hipSuccess)
+          inl_possible = false;
+        vv.pr = keep;
+      }
+      (void)hipGetLastError();
+    }
+    s->inline_tf = inl_possible && (size_t)(v.RS / 64) * (size_t)s->n_blocks <= 256;
+    if (const char* f = getenv("PEDN_INLINE_TF")) s->inline_tf = atoi(f) != 0 && inl_possible;
+    if (s->inline_tf) s->link_owner = 1;
     if (const char* f = getenv("PEDN_RL_OWNER")) s->rl_owner = atoi(f) != 0;
     // 0 = by batch: two chains where the step is not a pure chain of latencies any more -- from 4096 envs, and from 1024 with per-env
     // scenarios (45_intersections: 2048 envs plain 24.8-25.2 -> 24.7-25.7 us per env step, randomised 27.5-27.9 -> 25.6-26.0;
@@ -1281,14 +1317,19 @@ int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
   return PEDN_OK;
 }
 
-typedef void (*node_kernel_fn)(DevView, int);
 // lu: the instantiation whose slot waves perform the link update of step t-1 themselves (node_kernel<..., LU = true>)
-static node_kernel_fn node_kernel_for(const pedn_sim* s, bool lu = false) {
+static node_kernel_fn node_kernel_for(const pedn_sim* s, bool lu, bool tf) {
   const bool h = s->v.hist != 0;  // recent-history mode: the instantiations that mask the history rows
   const bool d6 = s->max_degree <= 6;  // loops and the row of turning fractions unrolled for 6 instead of 8 corridors per node
 #define PEDN_NK(PR_, W_, LP_, LU_) (h ? (d6 ? node_kernel<PR_, W_, LP_, true, 6, LU_> : node_kernel<PR_, W_, LP_, true, 8, LU_>) \
                                       : (d6 ? node_kernel<PR_, W_, LP_, false, 6, LU_> : node_kernel<PR_, W_, LP_, false, 8, LU_>))
   if (s->node_lp) return s->v.pr ? PEDN_NK(true, 6, true, false) : PEDN_NK(false, 6, true, false);   // at 8 waves the LP instantiations spill 4..14 vector registers
+  if (lu && tf) {   // the slot waves compute their own rows of turning fractions: 2 waves per SIMD (at 4 -- 128 VGPRs -- 59 vector spills)
+#define PEDN_NKT(PR_) (h ? (d6 ? node_kernel<PR_, 2, false, true, 6, true, true> : node_kernel<PR_, 2, false, true, 8, true, true>) \
+                         : (d6 ? node_kernel<PR_, 2, false, false, 6, true, true> : node_kernel<PR_, 2, false, false, 8, true, true>))
+    return s->v.pr ? PEDN_NKT(true) : PEDN_NKT(false);
+#undef PEDN_NKT
+  }
   if (lu) {
     if (s->v.pr) return s->lu_waves_pr == 8 ? PEDN_NK(true, 8, false, true) : PEDN_NK(true, 6, false, true);
     return s->lu_waves == 8 ? PEDN_NK(false, 8, false, true) : PEDN_NK(false, 6, false, true);
@@ -1376,7 +1417,8 @@ static void prewarm_chains(pedn_sim* s) {
   RlView q{};
   for (int c = 0; c < s->chains; ++c) {
     hipStream_t st = chain_stream(s, c);
-    for (int lu = 0; lu < 2; ++lu) hipLaunchKernelGGL(node_kernel_for(s, lu != 0), dim3(1, 1), dim3(512), s->node_lds, st, v, 2);
+    for (int lu = 0; lu < 2; ++lu) hipLaunchKernelGGL(node_kernel_for(s, lu != 0, false), dim3(1, 1), dim3(512), s->node_lds, st, v, 2);
+    if (s->inline_tf) hipLaunchKernelGGL(node_kernel_for(s, true, true), dim3(1, 1), dim3(512), s->node_lds_tf, st, v, 2);
     if (vl.hist) { hipLaunchKernelGGL((link_turn_kernel<false, false, 1, true>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
                    hipLaunchKernelGGL((link_kernel_1r<false, true>), dim3(1), dim3(256), 0, st, vl, 1); }
     else { hipLaunchKernelGGL((link_turn_kernel<false, false, 1, false>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
@@ -1397,16 +1439,21 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   lazy = lazy && !s->node_lp && v.n_pairs_corr > 0;
   // a pending link update is flushed when this is not the step it waits for, or when this step starts with the stand-alone turning
   // fractions (they read num_pedestrians[t - 1] as stored)
-  const bool tf_alone = v.n_trow > 0 && s->tp_ready != t;
+  // single-launch plan (inline_tf): node_kernel<LU, TF> computes the device-computed rows itself -- wherever it can be the LU kernel
+  const bool inl_plan = lazy && s->inline_tf && v.n_trow > 0;
+  const bool can_inl = inl_plan && s->link_pending == t - 1 && t >= 2;
+  const bool tf_alone = v.n_trow > 0 && s->tp_ready != t && !can_inl;
   const bool flush_now = s->link_pending >= 0 && (!(lazy && s->link_pending == t - 1) || tf_alone);
   const bool lu = lazy && s->link_pending == t - 1 && t >= 2 && !flush_now;   // (half 0 of a pair leaves link_pending as it is)
+  const bool inl = can_inl && lu;
   if (flush_now) flush_links(s, half, nullptr);
   DevView vn = v;                 // node_kernel's view: with the action rows when it applies the gater actions itself
   vn.rl_actions = fold_actions;
   const unsigned rgroups = (unsigned)(v.subRS / 64);
   // the turning fractions of t + 1 ride in the launch behind node_kernel(t) -- except behind the last step of the horizon, where
   // pair_pod / turn_tab have no row T + 1 to read (they hold T + 1 rows, 0..T) and nothing would consume the result
-  const bool groups = v.n_trow > 0, fused = groups && s->fuse_tp && t + 1 <= v.T1 - 1;
+  // (and not under the single-launch plan, where the next step computes its own rows)
+  const bool groups = v.n_trow > 0, fused = groups && s->fuse_tp && t + 1 <= v.T1 - 1 && !inl_plan;
   const bool obs_fused = observe >= 0 && s->rl_ready && s->fuse_obs;
   auto launch = [&](auto kernel, dim3 grid, dim3 block, int e, auto... args) {
     if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev[e], ev[e + 1], 0, args...);
@@ -1418,8 +1465,10 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     else { if (v.hist) launch(turn_frac_kernel<false, true>, dim3(nb), dim3(256), 0, v, t); else launch(turn_frac_kernel<false, false>, dim3(nb), dim3(256), 0, v, t); }
     s->tp_ran = 1;
   }
-  if (ev) hipExtLaunchKernelGGL(node_kernel_for(s, lu), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, ev[2], ev[3], 0, vn, t);
-  else hipLaunchKernelGGL(node_kernel_for(s, lu), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, stream, vn, t);
+  const size_t nlds = inl ? s->node_lds_tf : s->node_lds;
+  if (ev) hipExtLaunchKernelGGL(node_kernel_for(s, lu, inl), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), nlds, stream, ev[2], ev[3], 0, vn, t);
+  else hipLaunchKernelGGL(node_kernel_for(s, lu, inl), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), nlds, stream, vn, t);
+  if (inl && last_chain(s, half)) s->tp_ready = t;   // the fractions of t are in tfd[t & 1] (a following step that cannot inline computes its own)
   // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
   const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0 && !obs_fused) ? 2 : 1;   // (the diagnostic NS = 2 has no OBS instantiation)
   const bool one_r = v.pr || (s->link_ns == 0 && !fused && !obs_fused);   // one replica per lane (link_kernel_1r)
@@ -1476,7 +1525,7 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
   if (!s || !ms) return fail(s, PEDN_E_ARG, "null argument");
   if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
-  pending_links_first(s);
+  join_forked(s);   // (a pending link update is left to the first step of the range, as in pedn_run)
   // hipExtLaunchKernelGGL start/stop events carry the dispatch's own begin/end timestamps (what rocprofv3 reports),
   // not the enqueue-to-completion interval an ordinary hipEventRecord bracket would measure.
   hipEvent_t ev[6];
@@ -1556,7 +1605,7 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
 int pedn_plan_info(pedn_sim* s, int32_t* info, int32_t n) {
   if (!s || !info || n < 4) return fail(s, PEDN_E_ARG, "pedn_plan_info: null argument or fewer than 4 entries");
   info[0] = s->chains;
-  info[1] = s->link_owner && !s->node_lp && s->v.n_pairs_corr > 0;
+  info[1] = s->link_owner && !s->node_lp && s->v.n_pairs_corr > 0;   // (with device-computed rows: the single-launch plan, inline_tf)
   info[2] = s->stream_probe_attempts;
   info[3] = (int32_t)(s->stream_probe_ms * 1000.0f + 0.5f);
   return PEDN_OK;
@@ -1646,7 +1695,7 @@ int pedn_profile_run(pedn_sim* s, int32_t t0, int32_t t1, float ms[3], int32_t* 
   if (!s || !ms || !chains) return fail(s, PEDN_E_ARG, "null argument");
   if (t0 < 1 || t1 > s->v.T1 || t0 >= t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
-  pending_links_first(s);
+  join_forked(s);   // (a pending link update is left to the first step of the range, as in pedn_run)
   std::vector<ProfRow> rows;
   int ch = 1;
   const int rc = profile_range(s, t0, t1, rows, &ch);
@@ -1663,7 +1712,7 @@ int pedn_profile_timeline(pedn_sim* s, int32_t t0, int32_t t1, float* out, int32
   if (!s || !out || !n_rows || !chains) return fail(s, PEDN_E_ARG, "null argument");
   if (t0 < 1 || t1 > s->v.T1 || t0 >= t1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
-  pending_links_first(s);
+  join_forked(s);   // (a pending link update is left to the first step of the range, as in pedn_run)
   std::vector<ProfRow> rows;
   int ch = 1;
   const int rc = profile_range(s, t0, t1, rows, &ch);
@@ -2111,7 +2160,7 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
     const bool last = k == action_gap - 1;
     bool observed = false;
     // owner-wave plan of the RL step (rl_owner): only with the actions folded into node_kernel and the observations in the second launch
-    const bool lazy = !two && s->rl_owner && s->rl_fold && s->fuse_obs && (!actions || fold != nullptr);
+    const bool lazy = !two && (s->rl_owner || s->inline_tf) && s->rl_fold && s->fuse_obs && (!actions || fold != nullptr);
     if (two) {
       s->run_chains = 2;
       for (int c = 0; c < 2; ++c) launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, c, false);

@@ -291,22 +291,29 @@ __device__ __forceinline__ int as_vector(int x) {
 // the link update (link.py:133-136), so the parts of that launch do not depend on each other.
 // lds: PEDN_TF_LDS_DOUBLES doubles of the workgroup's LDS (the kernel owns the buffer: the parts of link_turn_kernel share one)
 #define PEDN_TF_LDS_DOUBLES ((PEDN_TF_LDS_ROWS + PEDN_MAX_DEGREE - 1) * 64)
-template <bool PR, bool FUSED, bool HIST>
-__device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned block, double* lds) {
+// INL: the row is computed by ONE wave of node_kernel for itself (the single-launch plan of small batches): `row` and `r0` are given,
+// `lds` is the wave's private share (PEDN_TF_INL_LDS doubles: its probabilities' LDS rows rebased to 0 -- the row record's word 109
+// holds the base the host gave the row inside its quad -- then PEDN_MAX_DEGREE - 1 rows in which the fractions are handed back), coop
+// rows do not come here.
+#define PEDN_TF_INL_LDS ((PEDN_TF_INL_ROWS + PEDN_MAX_DEGREE - 1) * 64)
+template <bool PR, bool FUSED, bool HIST, bool INL = false>
+__device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned block, double* lds, int inl_row = 0, int inl_r0 = 0,
+                                               int inl_w0 = 0, int inl_w1 = 0) {
   double* const sP = lds;                               // [PEDN_TF_LDS_ROWS][64] probabilities of the workgroup's rows
   double* const sAcc = lds + PEDN_TF_LDS_ROWS * 64;     // [PEDN_MAX_DEGREE - 1][64] coop rows: the turns' sums on their way to wave 0
   constexpr int NE = PEDN_MAX_DEGREE - 1;
   const int RS = v.RS;
   const unsigned rgroups = (unsigned)(v.subRS / 64);
   const int lane = (int)(threadIdx.x & 63);
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int row = (int)(block / rgroups) * 4 + wave;
-  const int r = v.sub0 + (int)(block % rgroups) * 64 + lane;
+  const int wave = INL ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int row = INL ? inl_row : (int)(block / rgroups) * 4 + wave;
+  const int r = INL ? inl_r0 + lane : v.sub0 + (int)(block % rgroups) * 64 + lane;
   if (row >= v.n_trow) return;  // wave-uniform; no barrier below
   const int* rw = v.trow_words + (size_t)row * PEDN_TROW_WORDS;
-  const int w0 = rw[lane], w1 = rw[64 + lane];
+  const int w0 = INL ? inl_w0 : rw[lane], w1 = INL ? inl_w1 : rw[64 + lane];   // INL: the caller fetched the record with its own batch of loads
   const int m = rdl(w0, 0), turn0 = rdl(w0, 1), grp0 = rdl(w0, 2), n_grp = rdl(w0, 3), Q0 = rdl(w0, 4), Q1 = rdl(w0, 5);
-  const int n_used = rdl(w0, 6), any_sep = rdl(w0, 7), overflow = rdl(w1, 43), coop = rdl(w1, 44), part = coop ? wave : 0;
+  const int n_used = rdl(w0, 6), any_sep = rdl(w0, 7), overflow = rdl(w1, 43), coop = INL ? 0 : rdl(w1, 44), part = coop ? wave : 0;
+  const int lds0 = INL ? rdl(w1, 45) : 0;   // first LDS row of this row inside its quad
   if (m < 0) return;  // padding record of a block with fewer than four rows
 #ifdef PEDN_PHASE_PROFILE
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -394,7 +401,7 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
   // ---- phase 2
   auto put_prob = [&](int q, double p) {
     if (q >= PEDN_TF_LDS_ROWS) v.ent_p[(size_t)(q - PEDN_TF_LDS_ROWS) * RS + r] = p;
-    else if (q >= 0) sP[q * 64 + lane] = p;
+    else if (q >= 0) sP[(q - lds0) * 64 + lane] = p;
   };
   auto pick = [&](int idx, float& k, double& c) {  // entry idx of the row record, -1: virtual link (:577-579)
     k = 0.0f;
@@ -514,11 +521,11 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
   }
   TPH(2, lane);
   // ---- phase 3
-  if (coop) __syncthreads();  // workgroup-uniform: the four waves hold the same row
+  if (!INL && coop) __syncthreads();  // workgroup-uniform: the four waves hold the same row
   double* out = v.tfd[t & 1];
   int chunk0 = 0;  // products [chunk0, chunk0 + 64) of the row are in pcode / pw
   auto prob_of = [&](int code) -> double {
-    return code < 0 ? 1.0 : code < PEDN_TF_LDS_ROWS ? sP[code * 64 + lane] : v.ent_p[(size_t)(code - PEDN_TF_LDS_ROWS) * RS + r];
+    return code < 0 ? 1.0 : code < PEDN_TF_LDS_ROWS ? sP[(code - lds0) * 64 + lane] : v.ent_p[(size_t)(code - PEDN_TF_LDS_ROWS) * RS + r];
   };
   auto turn_sum = [&](int jj) -> double {
     const int tq0 = rdl(w1, 20 + 3 * jj) - Q0, tq1 = rdl(w1, 21 + 3 * jj) - Q0, mode = rdl(w1, 22 + 3 * jj);
@@ -529,7 +536,7 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
       // every probability is the constant 1 or in LDS: four products per pass, no branch in between
       auto lds_prob = [&](int q) -> double {
         const int c = rdl(pcode, q);
-        const double e = sP[(c < 0 ? 0 : c) * 64 + lane];
+        const double e = sP[(c < 0 ? 0 : c - lds0) * 64 + lane];
         return c < 0 ? 1.0 : e;
       };
       int q = tq0;
@@ -560,7 +567,8 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
     return acc;
   };
   double rowsum = 0.0;
-  if (coop) {  // the turns shared out over the waves, their sums handed to wave 0 through LDS
+  double* const sOut = lds + PEDN_TF_INL_ROWS * 64;   // INL: [PEDN_MAX_DEGREE - 1][64] the row's fractions on their way back to node_kernel
+  if (!INL && coop) {  // the turns shared out over the waves, their sums handed to wave 0 through LDS
     for (int jj = part; jj < m - 1; jj += 4) sAcc[jj * 64 + lane] = turn_sum(jj);
     __syncthreads();
     if (part != 0) return;
@@ -569,10 +577,16 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
       out[(size_t)(turn0 + jj) * RS + r] = acc;
       rowsum = (jj == 0) ? acc : rowsum + acc;
     }
-  } else {
+  } else if (!INL) {
     for (int jj = 0; jj < m - 1; ++jj) {
       const double acc = turn_sum(jj);
       out[(size_t)(turn0 + jj) * RS + r] = acc;
+      rowsum = (jj == 0) ? acc : rowsum + acc;
+    }
+  } else {
+    for (int jj = 0; jj < m - 1; ++jj) {
+      const double acc = turn_sum(jj);
+      sOut[jj * 64 + lane] = acc;
       rowsum = (jj == 0) ? acc : rowsum + acc;
     }
   }
@@ -584,10 +598,20 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
     g_tphase[row * 8 + 5] = n_grp; g_tphase[row * 8 + 6] = nq; g_tphase[row * 8 + 7] = tph[0];
   }
 #endif
-  if (fabs(rowsum - 1) > 1e-3) {  // check_fractions, :700-714
+  if (!INL) {
+    if (fabs(rowsum - 1) > 1e-3) {  // check_fractions, :700-714
+      for (int jj = 0; jj < m - 1; ++jj) {
+        const double f = out[(size_t)(turn0 + jj) * RS + r];
+        out[(size_t)(turn0 + jj) * RS + r] = rowsum > 1e-6 ? f / rowsum : 1.0 / (double)(m - 1);
+      }
+    }
+  } else {  // the same on the wave's LDS rows, where node_kernel picks the fractions up; stored for the readers of tfd too
+    const bool fix = fabs(rowsum - 1) > 1e-3;
     for (int jj = 0; jj < m - 1; ++jj) {
-      const double f = out[(size_t)(turn0 + jj) * RS + r];
-      out[(size_t)(turn0 + jj) * RS + r] = rowsum > 1e-6 ? f / rowsum : 1.0 / (double)(m - 1);
+      const double a = sOut[jj * 64 + lane];
+      const double f = fix ? (rowsum > 1e-6 ? a / rowsum : 1.0 / (double)(m - 1)) : a;
+      out[(size_t)(turn0 + jj) * RS + r] = f;
+      sOut[jj * 64 + lane] = f;
     }
   }
   if (fl) atomicOr(&v.flags[r], fl);
@@ -697,7 +721,10 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // incoming link's rows, and carries on.  The gate record of a link (link.py:188) is written by the wave that holds the link as
 // its OUTGOING link: that wave loads the back gate anyway, and reads it before it applies an RL action to it.  pedn_run then needs
 // ONE launch per step (+ one trailing link_kernel for the last step of the range); see launch_step.
-template <bool PR, int WAVES, bool LP, bool HIST, int MD = PEDN_MAX_DEGREE, bool LU = false>
+// TF (with LU; the single-launch plan of small batches with dynamic turning fractions): a slot wave whose row of fractions is computed
+// on the device computes it ITSELF (turn_frac_body<.., INL>: from num_pedestrians[t-2] and the flows of t-1, the arithmetic the second
+// launch of step t-1 would have used), right behind its batch of loads -- no launch in front of or behind node_kernel.
+template <bool PR, int WAVES, bool LP, bool HIST, int MD = PEDN_MAX_DEGREE, bool LU = false, bool TF = false>
 __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   // dynamic LDS, sized by the host for the fullest block (pedn_create: node_lds): a block of nodes of degree 3..4 needs 24 of
   // the 64 tiles a single degree-8 node would
@@ -737,30 +764,27 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
     const double* tfrow = W.dyn == 1 ? v.tfd[t & 1] : (W.dyn == 2 ? v.turn_tab_r : v.tf);
     const double* tfu = W.dyn == 2 ? v.turn_tab + (size_t)t * v.n_turns : v.tf_u;
     const bool tf_shared = W.dyn == 2 ? v.pod_pr == 0 : (W.dyn == 0 && tfu[turn0] == tfu[turn0]);  // tf_u: NaN = per-replica rows
-    if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
-      s_i = v.demand[((size_t)W.demand_row * v.T1 + tp) * RS + r];
-      co_prev = rowp(v.f64[F_CO], R64(F_CO, tp), lin, Lall, RS, r0)[lane];
-      ci_prev = rowp(v.f64[F_CI], R64(F_CI, tp), lout, Lall, RS, r0)[lane];
-      if (kind == 1) {
-#pragma unroll
-        for (int jj = 0; jj < MD - 1; ++jj)
-          if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
-      }
-      r_i = 1e6;
-    } else {
-      const LinkP Pin = lane_params<PR>(v, W.Pin, lin, r);
-      const LinkP Pout = lane_params<PR>(v, W.Pout, lout, r);
-      const bool early = tp < Pin.fft;  // link.py:267-269: sending flow is 0 until the first pedestrians can arrive
+    // TF: the wave's own row of fractions (ONE call site: the function is large), handed over in the wave's LDS rows
+    double* const my_tf = pedn_lds + (TF ? v.tf_lds_off + wave * PEDN_TF_INL_LDS : 0);
+    const bool inl_row = TF && kind == 1 && W.dyn == 1 && W.trow >= 0;
+    // ---- the physical slot's parameters and its ONE batch of independent loads (see SlotIn): straight-line and unconditional so that
+    // the compiler issues them back to back (a load skipped by a branch costs a wait at the join); the few values of an `early` step are
+    // unused.  TF: issued BEFORE the wave computes its own row of fractions, so that the row's loads and arithmetic run under them.
+    LinkP Pin = W.Pin, Pout = W.Pout;
+    bool early = false;
+    int tm1 = 0, t_sw = 0;
+    SlotIn x;
+    double lu_ia = 0.0, lu_oa = 0.0, lu_ib = 0.0, lu_ob = 0.0, lu_npa = 0.0, lu_npb = 0.0;
+    float lu_pa = 0.0f, lu_pb = 0.0f, lu_rs = 0.0f, lu_old = 0.0f;
+    const bool lu_win = tp >= v.W;
+    auto load_batch = [&]() {
+      Pin = lane_params<PR>(v, W.Pin, lin, r);
+      Pout = lane_params<PR>(v, W.Pout, lout, r);
+      early = tp < Pin.fft;  // link.py:267-269: sending flow is 0 until the first pedestrians can arrive
       uint32_t flw = 0;
-      const int tm1 = wrap_idx(tp - 1, v.T1, flw);
+      tm1 = wrap_idx(tp - 1, v.T1, flw);
       fl |= flw;
-      // ---- one batch of independent loads (see SlotIn): straight-line and unconditional so that the compiler issues them
-      // back to back (a load skipped by a branch costs a wait at the join); the few values of an `early` step are unused
-      SlotIn x;
-      const int t_sw = tp + 1 - Pout.tau_sw > 0 ? tp + 1 - Pout.tau_sw : 0;
-      double lu_ia = 0.0, lu_oa = 0.0, lu_ib = 0.0, lu_ob = 0.0, lu_npa = 0.0, lu_npb = 0.0;
-      float lu_pa = 0.0f, lu_pb = 0.0f, lu_rs = 0.0f, lu_old = 0.0f;
-      const bool lu_win = tp >= v.W;
+      t_sw = tp + 1 - Pout.tau_sw > 0 ? tp + 1 - Pout.tau_sw : 0;
       if (!LU) {
         x.n_in = rowp(v.f32[G_N], R32(G_N, tp), lin, L, RS, r0)[lane];
         x.n_out = rowp(v.f32[G_N], R32(G_N, tp), lout, L, RS, r0)[lane];
@@ -784,7 +808,6 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       x.co_in = rowp(v.f64[F_CO], R64(F_CO, tp), lin, Lall, RS, r0)[lane];
       x.s_prev = rowp(v.f64[F_S], R64(F_S, tm1), lin, L, RS, r0)[lane];
       x.co_sw = rowp(v.f64[F_CO], R64(F_CO, t_sw), lout, Lall, RS, r0)[lane];
-      x.co_sw = t_sw > v.valid_hi ? 0.0 : x.co_sw;   // as for ci_look below
       x.ci_out = rowp(v.f64[F_CI], R64(F_CI, tp), lout, Lall, RS, r0)[lane];
       x.r_prev = rowp(v.f64[F_R], R64(F_R, tm1), lout, L, RS, r0)[lane];
       const double fu = v.front_u[lin], bu = v.back_u[lout];
@@ -792,6 +815,33 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
       x.back_out = bu == bu ? bu : v.back[(size_t)lout * RS + r];
       x.sepw_in = Pin.sep ? v.sepw[(size_t)lin * RS + r] : 0.0;
       x.sepw_out = Pout.sep ? v.sepw[(size_t)lout * RS + r] : 0.0;
+    };
+    int tw0 = 0, tw1 = 0;
+    if (inl_row) {   // the row's record: one vector load per half, in flight with the batch below
+      const int* rw = v.trow_words + (size_t)W.trow * PEDN_TROW_WORDS;
+      tw0 = rw[lane]; tw1 = rw[64 + lane];
+    }
+    if (TF && lin < L) load_batch();
+    if (inl_row) turn_frac_body<PR, true, HIST, true>(v, t, 0u, my_tf, W.trow, r0, tw0, tw1);
+    if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
+      s_i = v.demand[((size_t)W.demand_row * v.T1 + tp) * RS + r];
+      co_prev = rowp(v.f64[F_CO], R64(F_CO, tp), lin, Lall, RS, r0)[lane];
+      ci_prev = rowp(v.f64[F_CI], R64(F_CI, tp), lout, Lall, RS, r0)[lane];
+      if (kind == 1) {
+        if (inl_row) {
+#pragma unroll
+          for (int jj = 0; jj < MD - 1; ++jj)
+            if (jj < m - 1) tfr[jj] = my_tf[(PEDN_TF_INL_ROWS + jj) * 64 + lane];
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < MD - 1; ++jj)
+            if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
+        }
+      }
+      r_i = 1e6;
+    } else {
+      if (!TF) load_batch();
+      x.co_sw = t_sw > v.valid_hi ? 0.0 : x.co_sw;   // as for ci_look below
       const double lu_gate = x.back_out;
       if (v.rl_actions != nullptr && W.act >= 0 && r < v.R) {
         // ActionApplier for a gater (rl/builders.py:313-352: clip_gater_action_value + back_gate_width setter, link.py:121-126),
@@ -807,9 +857,15 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
         }
       }
       if (kind == 1) {
+        if (inl_row) {
 #pragma unroll
-        for (int jj = 0; jj < MD - 1; ++jj)
-          if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
+          for (int jj = 0; jj < MD - 1; ++jj)
+            if (jj < m - 1) tfr[jj] = my_tf[(PEDN_TF_INL_ROWS + jj) * 64 + lane];
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < MD - 1; ++jj)
+            if (jj < m - 1) tfr[jj] = tf_shared ? tfu[turn0 + jj] : tfrow[(size_t)(turn0 + jj) * RS + r];
+        }
       }
       if (LU) {
         // Network.update_link_states(t') for the incoming link (link.py:133-188); the speed noise needs none of the loads

@@ -38,7 +38,8 @@ struct SlotRec {  // one wave of node_kernel: a (node, slot) with everything sta
   // 2 turn_tab[t] / turn_tab_r (every product constant: replica-independent, tabulated and renormalised on the host)
   // act: action slot of the batched RL step that sets this slot's gate (back gate of lout = front gate of lin), -1 none
   // lp: index of the node among those that solve the node LP (assign_flows_type 'optimal'), on the node's slot 0, else -1
-  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, act, lp, pad0, pad1;
+  // trow: the slot's row record in trow_words when the row's turning fractions are computed on the device (dyn == 1), else -1
+  int32_t node, slot, base, m, kind, dyn, lin, lout, turn0, demand_row, act, lp, trow, pad1;
   LinkP Pin, Pout;  // parameters of the incoming / outgoing link of the slot (unused for a virtual pair)
 };
 
@@ -52,6 +53,7 @@ struct CorrRec {  // one lane group of link_kernel: both directions of a corrido
 // word k) and broadcast with v_readlane -- see turn_frac_body.
 #define PEDN_TF_LDS_ROWS 64    // LDS rows (64 lanes x 8 bytes) of one workgroup = 4 rows of dynamic nodes, shared out by the host
 #define PEDN_TROW_WORDS 128
+#define PEDN_TF_INL_ROWS 8     // LDS rows a slot wave of node_kernel<.., TF> has for the probabilities of its own row (single-launch plan)
 #define PEDN_TF_COOP_GROUPS 8   // rows with more multi-entry groups get a workgroup of their own (see turn_frac_body)
 // row record, PEDN_TROW_WORDS words (m = -1: padding):
 //   [0] m  [1] first turn of the row  [2] first group (index into tgrp_words / 32)  [3] number of multi-entry groups
@@ -62,6 +64,7 @@ struct CorrRec {  // one lane group of link_kernel: both directions of a corrido
 //       fraction is tabulated per step on the host)
 //   [107] 1: some probability of the row lives in ent_p instead of LDS
 //   [108] 1: coop -- the four records of this workgroup are the same row; its groups and turns are shared out over the waves
+//   [109] first LDS row of this row inside its workgroup (the inline variant rebases to it)
 // group record, 32 words (softmax group (od, up) with more than one downstream, update_node_turn_probs :561-589):
 //   [0] n  [1] allphys  [2 + e] entry of the row record the downstream link is (-1: virtual link, density 0, capacity 100)
 //   [9 + e] where P(down | up, od) goes: < 0 nowhere, < PEDN_TF_LDS_ROWS that LDS row of the workgroup, else row
@@ -108,6 +111,7 @@ struct DevView {
   // look-backs (link.py:205-212: Python's inflow[-k] = the untouched tail = 0): answered with the initial value instead of the row.
   // 0x7fffffff after an ordinary reset.
   int32_t valid_hi;
+  int32_t tf_lds_off;   // node_kernel<.., TF>: first double of the waves' private LDS rows for their own turning fractions (PEDN_TF_INL_ROWS each)
   int32_t pairs_adj;  // 1: corridor p is the links (2p, 2p + 1) -- the reference creates the two directions of an edge one after the other --
                       // so the link update forms its row addresses from p alone, without waiting for the corridor's record
   int32_t sub0, subRS;  // replicas [sub0, sub0 + subRS) are this launch's share (the whole batch, or one half of it per stream)

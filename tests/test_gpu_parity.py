@@ -184,7 +184,8 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
 
-    def history(fuse, waves, stepwise, general="0", lds_limit="64", md="6", link_ns="0", heavy="2", pairs_adj="1", owner="0"):
+    def history(fuse, waves, stepwise, general="0", lds_limit="64", md="6", link_ns="0", heavy="2", pairs_adj="1", owner="0", inline="0"):
+        monkeypatch.setenv("PEDN_INLINE_TF", inline)          # 1: the single-launch plan -- node_kernel<LU, TF>'s slot waves compute their own rows (where the model's rows allow)
         monkeypatch.setenv("PEDN_LINK_OWNER", owner)          # 1: pedn_run's owner-wave plan -- node_kernel<LU>(t + 1) performs the link update of t
         monkeypatch.setenv("PEDN_LU_WAVES", waves)
         monkeypatch.setenv("PEDN_PAIRS_ADJ", pairs_adj)        # 0: the link update takes its two link ids from the corridor's record (models whose
@@ -230,7 +231,10 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
                     ("0", "8", False, "0", "64", "8", "0", "2", "0", "1"), ("1", "6", False, "0", "64", "8", "2", "2", "1", "1"),
                     # step by step under the owner-wave plan: every network_loading(t) leaves its link update pending, the setter in
                     # between and the reads at the end perform it
-                    ("1", "8", True, "0", "64", "6", "0", "2", "1", "1"), ("0", "6", True, "0", "64", "8", "0", "2", "1", "1")):
+                    ("1", "8", True, "0", "64", "6", "0", "2", "1", "1"), ("0", "6", True, "0", "64", "8", "0", "2", "1", "1"),
+                    # the single-launch plan: ranges, single steps, step by step with setters and a reset
+                    ("1", "8", False, "0", "64", "6", "0", "2", "1", "1", "1"), ("1", "8", True, "0", "64", "6", "0", "2", "1", "1", "1"),
+                    ("0", "8", False, "0", "64", "8", "0", "2", "0", "1", "1")):
         got = history(*variant)
         for f in ALL_FIELDS:
             assert np.array_equal(ref[f], got[f]), (variant, f)
@@ -529,12 +533,14 @@ def test_two_stream_plan_gives_identical_histories(name, steps, hist, owner, mon
         assert np.array_equal(a[f], a2[f]), f             # the second episode repeats the first
 
 
-def test_profile_run_uses_and_reports_the_launch_plan():
+def test_profile_run_uses_and_reports_the_launch_plan(monkeypatch):
     """pedn_profile_run steps the simulation under pedn_run's plan with every launch timed: the plan it reports follows
-    pedn_set_streams and the length of the range, and the histories equal an untimed run's."""
+    pedn_set_streams and the length of the range, and the histories equal an untimed run's.  (The two-launch plan: this small batch
+    would otherwise step under the single-launch plan, one launch per step -- checked at the end.)"""
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
 
+    monkeypatch.setenv("PEDN_INLINE_TF", "0")
     np.random.seed(7)
     net = NetworkEnvGenerator(DATA).create_network("nine_intersections", verbose=False, n_replicas=256, rng_seed=11)
     e = net.engine()
@@ -559,6 +565,19 @@ def test_profile_run_uses_and_reports_the_launch_plan():
         assert np.array_equal(timed[f], e.read_block(LINK_FIELDS[f][0], 0, 80)), f
     with pytest.raises(Exception):
         e.set_streams(3)
+    net.close()
+    # the single-launch plan: node_kernel<LU, TF> alone per step, one link update behind the range
+    monkeypatch.setenv("PEDN_INLINE_TF", "1")
+    np.random.seed(7)
+    net = NetworkEnvGenerator(DATA).create_network("nine_intersections", verbose=False, n_replicas=256, rng_seed=11)
+    e = net.engine()
+    assert e.plan_info()["link_update_by_next_node_kernel"]
+    net.run(1, 10, check=False)                   # (a check of the error flags would perform the pending link update)
+    rows, chains = e.profile_timeline(10, 30)
+    assert chains == 1 and rows.shape == (20 + 1, 5) and list(rows[:-1, 2]) == [1.0] * 20 and rows[-1, 2] == 2.0
+    one = {f: e.read_block(LINK_FIELDS[f][0], 0, 30) for f in ALL_FIELDS}
+    for f in ALL_FIELDS:                          # (sending / receiving flow of step t are entries t - 1: entry 29 is step 30's)
+        assert np.array_equal(one[f][:29], timed[f][:29]), f
     net.close()
 
 

@@ -51,18 +51,20 @@ def kernel_metadata(tmp_path):
 #   pattern -> (max VGPRs = waves per SIMD it must keep, max LDS bytes = workgroups per CU, may spill scalar registers?)
 BUDGETS = {
     # shared link parameters, classic node model: 8 waves per SIMD; scalar spills go to VGPR lanes (cheap), vector spills to scratch
-    r"node_kernel<false, 8, false, (true|false), 6, false>": (64, None, True),
+    r"node_kernel<false, 8, false, (true|false), 6, false, false>": (64, None, True),
     # the same with the link update of the previous step performed by the slot waves (pedn_run's owner-wave plan): still 8 waves
-    r"node_kernel<false, 8, false, (true|false), 6, true>": (64, None, True),
-    r"node_kernel<false, 6, false, (true|false), 8, true>": (80, None, True),
-    r"node_kernel<true, 6, false, (true|false), 6, true>": (80, None, False),
+    r"node_kernel<false, 8, false, (true|false), 6, true, false>": (64, None, True),
+    r"node_kernel<false, 6, false, (true|false), 8, true, false>": (80, None, True),
+    r"node_kernel<true, 6, false, (true|false), 6, true, false>": (80, None, False),
+    # the single-launch plan of small batches (the slot waves compute their own rows of turning fractions): one block per CU, no scratch
+    r"node_kernel<(true|false), 2, false, (true|false), \d, true, true>": (256, None, True),
     # networks with a node of 7 or 8 corridors (loops unrolled for 8): launched at 6 waves per SIMD (pedn_create: node_waves)
-    r"node_kernel<false, 6, false, (true|false), 8, false>": (80, None, True),
+    r"node_kernel<false, 6, false, (true|false), 8, false, false>": (80, None, True),
     # per-replica link parameters (randomised RL resets, ensembles): launched at 6 waves per SIMD (pedn_create: node_waves_pr) --
     # at 8 it spilled 2..8 vector registers; no spill of either kind, 6 waves (<= 80 VGPRs)
-    r"node_kernel<true, 6, false, (true|false), \d, false>": (80, None, False),
+    r"node_kernel<true, 6, false, (true|false), \d, false, false>": (80, None, False),
     # the node LP (assign_flows_type 'optimal'): launched at 6 waves per SIMD as well (at 8 it spilled 4..14 vector registers)
-    r"node_kernel<(true|false), 6, true, (true|false), \d, false>": (80, None, True),
+    r"node_kernel<(true|false), 6, true, (true|false), \d, false, false>": (80, None, True),
     # second launch of a step with dynamic turning fractions and / or observations: 4 waves per SIMD, 4 workgroups per CU by LDS
     # (the OBS instantiation was at 131-133 VGPRs / 42.5 KB = 3 until the parts shared one LDS buffer)
     r"link_turn_kernel<(true|false), (true|false), 1, (true|false)>": (128, 40960, True),

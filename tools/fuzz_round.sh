@@ -36,6 +36,9 @@ part_b() {
   PEDN_LINK_OWNER=1 PEDN_NODE_MD=8 python3 -u tools/gpu_fuzz.py $((S+4100*K)) $((S+4200*K))
   PEDN_LINK_OWNER=0 python3 -u tools/gpu_fuzz.py $((S+4200*K)) $((S+4400*K))
   PEDN_LINK_OWNER=1 python3 -u tools/gpu_fuzz_chains.py $((S+4400*K)) $((S+4500*K))
+  echo "# the single-launch plan of small batches (node_kernel<LU, TF>: the slot waves compute their own rows of turning fractions) is the"
+  echo "# default for these 3-replica networks wherever their rows allow it, i.e. in every campaign above; here forced OFF:"
+  PEDN_INLINE_TF=0 python3 -u tools/gpu_fuzz.py $((S+4500*K)) $((S+4800*K))
   echo "# assign_flows_type 'optimal' (node LP):"
   PEDN_FUZZ_OPTIMAL=1 python3 -u tools/gpu_fuzz.py $((S+1500*K)) $((S+1700*K))
   echo "# tools/gpu_fuzz_rl.py: observations and rewards of the batched RL step against the restated RL glue:"

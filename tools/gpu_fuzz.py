@@ -91,4 +91,4 @@ for seed in range(lo, hi):
         assert np.array_equal(tf, o.tf()), (seed, r)
         ran += 1
     net.close()
-print(f"{'per-replica scenarios, ' if per_replica else ''}fuse_tp={os.environ.get('PEDN_FUSE_TP','auto')} link_owner={os.environ.get('PEDN_LINK_OWNER','auto')} lu_waves={os.environ.get('PEDN_LU_WAVES','auto')} seeds {lo}..{hi}: {ran} replica runs bit-exact, {flagged} stopped at a reference raise site (same flag on both sides), {skipped} networks skipped (KeyError like the reference)")
+print(f"{'per-replica scenarios, ' if per_replica else ''}fuse_tp={os.environ.get('PEDN_FUSE_TP','auto')} link_owner={os.environ.get('PEDN_LINK_OWNER','auto')} lu_waves={os.environ.get('PEDN_LU_WAVES','auto')} inline_tf={os.environ.get('PEDN_INLINE_TF','auto')} seeds {lo}..{hi}: {ran} replica runs bit-exact, {flagged} stopped at a reference raise site (same flag on both sides), {skipped} networks skipped (KeyError like the reference)")
