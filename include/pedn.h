@@ -196,8 +196,9 @@ int pedn_get_widths(pedn_sim* sim, int32_t which, double* values);
 int pedn_step(pedn_sim* sim, int32_t t);
 /* steps t0 .. t1-1 enqueued back to back, t1 <= T+1; asynchronous.  Same results as t1 - t0 calls of pedn_step, under the launch
  * plan the engine picked for the model (pedn_plan_info): for a model without device-computed turning fractions the slot waves of
- * step t + 1's node kernel perform Network.update_link_states(t) (network.py:257-264) themselves -- ONE launch per step, plus one
- * link-update launch for the last step of the range, so every history row of steps < t1 is complete when the call's work is. */
+ * step t + 1's node kernel perform Network.update_link_states(t) (network.py:257-264) themselves -- ONE launch per step; small batches
+ * of models with short dynamic rows step the same way, the slot waves computing their own rows of turning fractions too.  The link
+ * update of the last step launched stays pending until the next step or the first call that looks at or changes the state. */
 int pedn_run(pedn_sim* sim, int32_t t0, int32_t t1);
 int pedn_synchronize(pedn_sim* sim);
 /* synchronises; flags[n_replicas] may be NULL; returns the OR over replicas (>= 0) or a negative code */
