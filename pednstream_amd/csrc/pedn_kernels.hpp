@@ -6,7 +6,11 @@
 //                     sending flow of the slot's incoming link, receiving flow of its outgoing link, the node's flow
 //                     distribution through LDS, cumulative counts
 //                                                                 node.py:164-221,230-242,272-300; link.py:216-416
-//   link_kernel_1r    the launch behind it when no node has dynamic fractions: one lane per (corridor = link pair, replica):
+//                     <LU>: the slot wave first performs the link update of step t-1 for its incoming link (every input was written
+//                     by earlier launches): ONE launch per step for models without device-computed fractions (pedn_hip.hip: launch_step)
+//                     <LU, TF>: and computes its own row of turning fractions too (small batches of models with short dynamic rows)
+//   link_kernel_1r    the launch behind it under the two-launch plan when no node has dynamic fractions -- and the one that performs a
+//                     link update still pending under the owner-wave plan: one lane per (corridor = link pair, replica):
 //                     pedestrians, density, fundamental diagram, travel time and its moving average
 //                                                                                       link.py:133-188; functions.py:112-134
 //                     (link_kernel<NS>: the same with two replicas per lane in NS segments of 128 replicas, PEDN_LINK_NS)
@@ -14,7 +18,8 @@
 //                     lane | turning fractions of t+1, short rows | RL observations of t] as independent workgroups
 //   turn_frac_kernel  the turning fractions on their own (first step of an episode): one wave per (row of a dynamic node, 64
 //                     replicas): logit route choice -> the row's turning fractions      path_finder.py:561-737
-// plus the batched RL glue (rl_apply_kernel, rl_observe_kernel), state initialisation and host<->device helpers.
+// plus the batched RL glue (rl_apply_kernel, rl_observe_kernel), the per-replica scenario randomisers (rand_*_kernel, pod_*_kernel),
+// state initialisation and host<->device helpers.
 #pragma once
 #include "pedn_math.hpp"
 #include "pedn_types.hpp"
