@@ -294,6 +294,9 @@ static int catch_up(pedn_sim* s, int upto) {
     const int a = s->valid_hi + 1, b = upto + 1;
     for (int f = 0; f < 4; ++f) HIP_TRY(s, hipMemsetAsync(v.f64[f] + (size_t)a * v.Lall * v.RS, 0, (size_t)(b - a) * v.Lall * v.RS * sizeof(double), s->stream));
     if (v.L > 0) {
+      // sending / receiving flow of step t are entries t - 1: entry valid_hi belongs to the step that is being skipped
+      const size_t n_1 = (size_t)v.L * v.RS;
+      hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n_1 + 255) / 256)), dim3(256), 0, s->stream, view, s->valid_hi, 1, 16);
       const size_t n_l = (size_t)(b - a) * v.L * v.RS;
       hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0, s->stream, view, a, b - a, 8);
       rc = hipGetLastError() == hipSuccess ? PEDN_OK : fail(s, PEDN_E_DEVICE, "init_state_kernel");

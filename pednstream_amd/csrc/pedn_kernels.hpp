@@ -1378,8 +1378,9 @@ __global__ void init_state_kernel(DevView v, int row0, int n_rows, int what) {
   auto has64 = [&](int f) { return t <= v.m64[f]; };  // rows of a field = mask + 1 (a ring), or all of max_rows
   auto has32 = [&](int g) { return t <= v.m32[g]; };
   const bool rest = (what & 8) != 0, all = (what & 1) != 0 || rest;
-  if (all && has64(F_S)) v.f64[F_S][i] = -1.0;
-  if (all && has64(F_R)) v.f64[F_R][i] = -1.0;
+  const bool sr = all || (what & 16) != 0;   // bit 4: only sending / receiving flow
+  if (sr && has64(F_S)) v.f64[F_S][i] = -1.0;
+  if (sr && has64(F_R)) v.f64[F_R][i] = -1.0;
   if (((all && !rest) || (what & 4)) && has64(F_GATE)) v.f64[F_GATE][i] = P.width;  // link.py:56
   if (all && has32(G_TT)) v.f32[G_TT][i] = t == 0 ? P.tt0 : 0.0f;
   // link.py:91: avg_travel_time[t] = travel_time[0] for t < W; the link update only writes it from t = W on, so the slots

@@ -270,8 +270,10 @@ def test_four_chain_plan_gives_identical_histories(name, steps, owner, monkeypat
         assert np.array_equal(a[f], b[f]), f
 
 
-@pytest.mark.parametrize("name,steps1,steps2", [("nine_intersections", 260, 90), ("long_corridor", 200, 70), ("melbourne", 120, 40), ("delft", 60, 25)])
-def test_lazy_reset_serves_a_second_episode_like_a_fresh_engine(name, steps1, steps2):
+@pytest.mark.parametrize("name,steps1,steps2,R,streams", [("nine_intersections", 260, 90, 64, "1"), ("long_corridor", 200, 70, 64, "1"),
+                                                          ("melbourne", 120, 40, 64, "1"), ("delft", 60, 25, 64, "1"),
+                                                          ("melbourne", 90, 40, 256, "2"), ("nine_intersections", 150, 60, 256, "2")])
+def test_lazy_reset_serves_a_second_episode_like_a_fresh_engine(name, steps1, steps2, R, streams, monkeypatch):
     """pedn_reset_lazy restores only what a new episode reads before it writes and declares every other row unwritten.  A second,
     DIFFERENT and shorter episode on the same engine must equal that episode on a fresh engine in every row of every field -- the rows
     behind its last step included, which still hold the first episode's values in memory: reads answer them with the initial values,
@@ -280,14 +282,17 @@ def test_lazy_reset_serves_a_second_episode_like_a_fresh_engine(name, steps1, st
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
 
+    monkeypatch.setenv("PEDN_STREAMS", streams)          # 2: the halves of the batch as two chains of launches (the catch-up clears
+    monkeypatch.setenv("PEDN_STREAM_PROBE", "0")         # run before the fork, the bookkeeping once per step)
+
     def build():
         np.random.seed(7)
-        return NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=64, rng_seed=11)
+        return NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=R, rng_seed=11)
 
     def demand(net, key, scale):
         T = net.simulation_steps
         for nid in net.origin_nodes:
-            rows = np.stack([np.random.default_rng(key + 7 * r + 1000 * int(nid)).poisson(scale, T).astype(np.float64) for r in range(64)])
+            rows = np.stack([np.random.default_rng(key + 7 * r + 1000 * int(nid)).poisson(scale, T).astype(np.float64) for r in range(R)])
             net.set_demand_matrix(nid, rows)
 
     def everything(net, upto):
@@ -315,6 +320,7 @@ def test_lazy_reset_serves_a_second_episode_like_a_fresh_engine(name, steps1, st
     for net in (a, b):
         net.engine().step(steps2 + 3)
         net.engine().step(steps2 + 4)
+        net.run(steps2 + 9, steps2 + 20, check=False)       # another jump, into a range long enough for two chains
     got, want = everything(a, T + 1), everything(b, T + 1)
     for f in want:
         assert np.array_equal(got[f], want[f]), f
