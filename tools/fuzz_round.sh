@@ -39,6 +39,8 @@ part_b() {
   echo "# the single-launch plan of small batches (node_kernel<LU, TF>: the slot waves compute their own rows of turning fractions) is the"
   echo "# default for these 3-replica networks wherever their rows allow it, i.e. in every campaign above; here forced OFF:"
   PEDN_INLINE_TF=0 python3 -u tools/gpu_fuzz.py $((S+4500*K)) $((S+4800*K))
+  echo "# lazy reset against the ordinary reset under random sequences of calls (tools/gpu_fuzz_lazy.py):"
+  python3 -u tools/gpu_fuzz_lazy.py $((S+5000*K)) $((S+5200*K))
   echo "# assign_flows_type 'optimal' (node LP):"
   PEDN_FUZZ_OPTIMAL=1 python3 -u tools/gpu_fuzz.py $((S+1500*K)) $((S+1700*K))
   echo "# tools/gpu_fuzz_rl.py: observations and rewards of the batched RL step against the restated RL glue:"
