@@ -1213,6 +1213,9 @@ int pedn_set_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, const
   if (rc != PEDN_OK) return rc;
   // a dynamic node recomputes its fractions every step (network.py:272-275); until then a read returns what was imposed
   s->h_tf_set_epoch[node] = s->step_epoch;
+  // (the imposed values go into the buffer of the last step too, see below: a REPEAT of that step must recompute them, not take them
+  // for its own -- under the single-launch plan tp_ready names that very step; found by tools/gpu_fuzz_plans.py)
+  if (s->h_node_dyn[node]) s->tp_ready = -1;
   if (s->h_node_dyn[node] && s->last_t >= 0 && (rc = push_rows(s, s->v.tfd[s->last_t & 1], tf, n, (size_t)a, 1, replica)) != PEDN_OK) return rc;
   for (int k = 0; k < n; ++k)
     s->h_tf_u[a + k] = (replica == PEDN_ALL && !s->h_node_dyn[node]) ? tf[k] : __builtin_nan("");

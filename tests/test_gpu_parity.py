@@ -240,6 +240,42 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
             assert np.array_equal(ref[f], got[f]), (variant, f)
 
 
+def test_repeated_step_after_imposed_fractions_recomputes_them_under_every_plan(monkeypatch):
+    """update_turning_fractions_per_node on a dynamic node, then the LAST step again: the node recomputes its fractions at every
+    network_loading (network.py:272-275), so the repeat must not take the imposed values that a read of the last step's buffer returns.
+    Under the single-launch plan that buffer is the one the repeated step would reuse (found by tools/gpu_fuzz_plans.py, seed 950153)."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    def history(plain):
+        for k in ("PEDN_LINK_OWNER", "PEDN_INLINE_TF"):
+            monkeypatch.setenv(k, "0") if plain else monkeypatch.delenv(k, raising=False)
+        np.random.seed(7)
+        net = NetworkEnvGenerator(DATA).create_network("nine_intersections", verbose=False, n_replicas=64, rng_seed=11)
+        nd = next(n for n in net.nodes.values() if len(n.incoming_links) > 2 and len(n.incoming_links) == len(n.outgoing_links))
+        m = len(nd.incoming_links)
+        for t in range(1, 30):
+            net.network_loading(t)
+        tf = np.random.default_rng(3).dirichlet(np.ones(m - 1), size=m).reshape(-1)
+        net.update_turning_fractions_per_node([nd.node_id], [tf])
+        seen = net.engine().get_turning_fractions(nd.index, 0).copy()      # the imposed values until the next step
+        net.engine().step(29)                                               # the last step again
+        for t in range(30, 60):
+            net.network_loading(t)
+        e = net.engine()
+        out = {f: e.read_block(LINK_FIELDS[f][0], 0, 60) for f in ALL_FIELDS}
+        info = e.plan_info()
+        net.close()
+        return out, seen, info
+
+    ref, seen_ref, _ = history(True)
+    got, seen, info = history(False)
+    assert info["link_update_by_next_node_kernel"], info
+    assert np.array_equal(seen, seen_ref)
+    for f in ALL_FIELDS:
+        assert np.array_equal(ref[f], got[f]), f
+
+
 @pytest.mark.parametrize("name,steps,owner", [("melbourne", 50, "1"), ("nine_intersections", 90, "0"), ("delft", 30, "0")])
 def test_four_chain_plan_gives_identical_histories(name, steps, owner, monkeypatch):
     """PEDN_STREAMS=4: the quarters of the batch as four chains of launches on four streams (pedn_set_streams(4)).  Whether the runtime
