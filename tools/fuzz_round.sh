@@ -41,6 +41,8 @@ part_b() {
   PEDN_INLINE_TF=0 python3 -u tools/gpu_fuzz.py $((S+4500*K)) $((S+4800*K))
   echo "# lazy reset against the ordinary reset under random sequences of calls (tools/gpu_fuzz_lazy.py):"
   python3 -u tools/gpu_fuzz_lazy.py $((S+5000*K)) $((S+5200*K))
+  echo "# the engine's own launch plans against two launches per step on one stream under random sequences of calls (tools/gpu_fuzz_plans.py):"
+  python3 -u tools/gpu_fuzz_plans.py $((S+5200*K)) $((S+5600*K))
   echo "# assign_flows_type 'optimal' (node LP):"
   PEDN_FUZZ_OPTIMAL=1 python3 -u tools/gpu_fuzz.py $((S+1500*K)) $((S+1700*K))
   echo "# tools/gpu_fuzz_rl.py: observations and rewards of the batched RL step against the restated RL glue:"
