@@ -53,6 +53,8 @@ extern "C" {
 #define PEDN_F_NEG_BINOM 8u   /* binomial with n < 0               (numpy ValueError at link.py:382) */
 #define PEDN_F_SAME_STEP 16u  /* look-back of 0 steps: the reference result depends on node iteration order */
 #define PEDN_F_LP 32u         /* node LP (assign_flows_type 'optimal') did not terminate: `res.success` false, node.py:267 */
+#define PEDN_F_PLACEMENT 64u  /* persistent plan of pedn_run: a replica group's workgroups were not placed on one XCD, or one of them
+                                 never arrived -- the numbers of these replicas are invalid (the plan is opt-in: PEDN_PERSIST=1) */
 
 /* RNG modes (oracle/rng_contract.py) */
 #define PEDN_RNG_PHILOX 0
@@ -245,7 +247,10 @@ int pedn_set_streams(pedn_sim* sim, int32_t n);
 /* The launch plan of pedn_run: info[0] = chains (1 | 2 | 4), info[1] = 1 when the link update is performed by the next step's node kernel
  * (one launch per step), info[2] = streams created until one was found that overlaps with the engine's stream (0: not probed yet;
  * the runtime may map two streams onto one hardware queue, which would serialise the chains), info[3] = duration in microseconds of
- * the probe's two concurrent 300 us kernels on the pair kept (~300: they overlap, ~600: they do not); n = entries of info (>= 4). */
+ * the probe's two concurrent 300 us kernels on the pair kept (~300: they overlap, ~600: they do not); n = entries of info (>= 4);
+ * with n >= 5: info[4] = 1 when ranges of three and more steps run as ONE persistent launch (small networks in full-record mode: the
+ * workgroups of a replica group meet between steps inside one XCD; opt-in with PEDN_PERSIST=1 -- measured no faster than a
+ * launch per step --, PEDN_F_PLACEMENT). */
 int pedn_plan_info(pedn_sim* sim, int32_t* info, int32_t n);
 
 /* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */

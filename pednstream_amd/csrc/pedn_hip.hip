@@ -43,6 +43,12 @@ struct pedn_sim {
   std::vector<int32_t> h_slot_trow;
   int rl_chains = 0;   // pedn_rl_step steps the two halves of the envs as two chains that stay forked ACROSS calls (PEDN_RL_CHAINS)
   int forked = 0;      // stream2 holds work of such a chain that the engine's stream does not order yet (join_forked)
+  // Persistent plan (node_persist_kernel): pedn_run's ranges of small networks in ONE launch -- the workgroups of a replica group meet
+  // between steps at a counter inside one XCD.  Eligible: the owner-wave / single-launch plan, full-record mode, the whole padded grid
+  // resident at once (<= 256 workgroups).  PEDN_PERSIST=1 (off by default: no faster than a launch per step, see the kernel).
+  int persist = 0;
+  unsigned* d_persist_bar = nullptr;   // [groups][32]: arrivals, XCC id
+  unsigned persist_base = 0;           // value of every group's arrival counter before the next launch
   int valid_hi = 0x7fffffff;   // lazy reset: history rows above this index are neither written nor cleared (DevView.valid_hi)
   int link_pending = -1;  // owner-wave plan: step whose link update has not been performed yet, -1 none
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
@@ -455,6 +461,8 @@ static inline void pending_links_first(pedn_sim* s);
 static inline void join_forked(pedn_sim* s);
 typedef void (*node_kernel_fn)(DevView, int);
 static node_kernel_fn node_kernel_for(const pedn_sim* s, bool lu, bool tf);
+typedef void (*persist_kernel_fn)(DevView, int, int, unsigned*, unsigned, int, int);
+static persist_kernel_fn persist_kernel_for(const pedn_sim* s);
 static void prewarm_chains(pedn_sim* s);
 
 int pedn_abi_version(void) { return PEDN_ABI_VERSION; }
@@ -1008,6 +1016,26 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     int rc = reset_state(s);
     if (rc != PEDN_OK) { std::string keep = g_last_error; pedn_destroy(s); g_last_error = keep; return rc; }
   }
+  {  // persistent plan: see node_persist_kernel
+    const size_t groups = (size_t)v.RS / 64, padded = (groups + 7) / 8 * 8 * (size_t)s->n_blocks;
+    bool ok = s->link_owner && !s->node_lp && v.n_pairs_corr > 0 && !v.hist && padded <= 256 && (v.n_trow == 0 || s->inline_tf);
+    if (ok && (v.n_trow > 0 ? s->node_lds_tf : s->node_lds) > 64 * 1024)
+      for (int pr = 0; pr < 2 && ok; ++pr) {
+        const int keep = v.pr;
+        v.pr = pr;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(persist_kernel_for(s)), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(v.n_trow > 0 ? s->node_lds_tf : s->node_lds)) != hipSuccess) ok = false;
+        v.pr = keep;
+        (void)hipGetLastError();
+      }
+    s->persist = 0;   // opt-in: a measured negative (see node_persist_kernel)
+    if (const char* f = getenv("PEDN_PERSIST")) s->persist = atoi(f) != 0 && ok;
+    if (s->persist) {
+      std::vector<unsigned> h(groups * 32, 0u);
+      for (size_t g = 0; g < groups; ++g) h[g * 32 + 1] = 0xffffffffu;
+      TRY(upload(s, h.data(), h.size(), (const unsigned**)&s->d_persist_bar));
+    }
+  }
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   if (s->chains > 1) {
     int got = 1;
@@ -1345,6 +1373,18 @@ static node_kernel_fn node_kernel_for(const pedn_sim* s, bool lu, bool tf) {
 #undef PEDN_NK
 }
 
+// full-record mode only; built for 2 waves per SIMD (one workgroup per CU is all the plan ever places; at 6 the loop-carried kernel
+// arguments cost 270 B of scratch per lane)
+static persist_kernel_fn persist_kernel_for(const pedn_sim* s) {
+  const bool d6 = s->max_degree <= 6;
+  if (s->v.n_trow > 0) {
+    if (s->v.pr) return d6 ? node_persist_kernel<true, 2, false, 6, true> : node_persist_kernel<true, 2, false, 8, true>;
+    return d6 ? node_persist_kernel<false, 2, false, 6, true> : node_persist_kernel<false, 2, false, 8, true>;
+  }
+  if (s->v.pr) return d6 ? node_persist_kernel<true, 2, false, 6, false> : node_persist_kernel<true, 2, false, 8, false>;
+  return d6 ? node_persist_kernel<false, 2, false, 6, false> : node_persist_kernel<false, 2, false, 8, false>;
+}
+
 // The link update of step t as a launch of its own (the second launch of a step of a model without dynamic turning fractions, and
 // the flush of a pending update under the owner-wave plan).  e >= 0: start / stop events ev[e], ev[e + 1].
 static unsigned link_blocks(const pedn_sim* s, const DevView& v, bool one_r, int ns) {
@@ -1589,7 +1629,8 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
   // link update of t - 1 -- plus one link_kernel for the last step of the range.
   const bool lazy = s->link_owner != 0;
   join_forked(s);
-  const int nch = chains_for(s, t0, t1);
+  const bool persist = s->persist && lazy && t1 - t0 >= 3;
+  const int nch = persist ? 1 : chains_for(s, t0, t1);
   if (nch > 1) {
     if (s->link_pending >= 0 && s->link_pending != t0 - 1) pending_links_first(s);   // a stale pending update: on the whole batch, before the fork
     if (t0 - 1 > s->valid_hi) catch_up(s, t0 - 1);
@@ -1601,6 +1642,26 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
     s->run_chains = 1;
     rc = join_chains(s, nch);    // the last step's link update stays pending on the joined stream (pending_links_first)
     if (rc != PEDN_OK) return rc;
+  } else if (persist) {
+    // persistent plan: the first step as a launch of its own unless it is the step the pending link update waits for, the rest of
+    // the range in ONE launch (every step of it is node_kernel<LU[, TF]>'s), the last step's link update stays pending as always
+    int t = t0;
+    if (!(s->link_pending == t - 1 && t >= 2)) launch_step(s, t++, nullptr, -1, nullptr, nullptr, -1, lazy);
+    DevView& v = s->v;
+    if (s->valid_hi != 0x7fffffff) {   // after a lazy reset: the rows of the range are cleared now (the kernel's view cannot move with t)
+      const int rc = catch_up(s, t1 - 1);
+      if (rc != PEDN_OK) return rc;
+    }
+    const int groups = v.RS / 64, nb = s->n_blocks;
+    const unsigned grid = (unsigned)((groups + 7) / 8 * 8 * nb);
+    const size_t nlds = v.n_trow > 0 ? s->node_lds_tf : s->node_lds;
+    hipLaunchKernelGGL(persist_kernel_for(s), dim3(grid), dim3(512), nlds, s->stream, v, t, t1, s->d_persist_bar, s->persist_base, nb, groups);
+    s->persist_base += (unsigned)nb * (unsigned)(t1 - t - 1);
+    if (v.n_trow > 0) s->tp_ready = t1 - 1;
+    s->link_pending = t1 - 1;
+    if (s->valid_hi != 0x7fffffff && t1 - 1 > s->valid_hi) s->valid_hi = v.valid_hi = t1 - 1;
+    s->last_t = t1 - 1;
+    s->step_epoch += t1 - t;
   } else {
     for (int t = t0; t < t1; ++t) launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, lazy);
   }
@@ -1614,6 +1675,7 @@ int pedn_plan_info(pedn_sim* s, int32_t* info, int32_t n) {
   info[1] = s->link_owner && !s->node_lp && s->v.n_pairs_corr > 0;   // (with device-computed rows: the single-launch plan, inline_tf)
   info[2] = s->stream_probe_attempts;
   info[3] = (int32_t)(s->stream_probe_ms * 1000.0f + 0.5f);
+  if (n >= 5) info[4] = s->persist;   // ranges of pedn_run as one persistent launch
   return PEDN_OK;
 }
 

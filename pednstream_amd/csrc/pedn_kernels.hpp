@@ -729,27 +729,24 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // TF (with LU; the single-launch plan of small batches with dynamic turning fractions): a slot wave whose row of fractions is computed
 // on the device computes it ITSELF (turn_frac_body<.., INL>: from num_pedestrians[t-2] and the flows of t-1, the arithmetic the second
 // launch of step t-1 would have used), right behind its batch of loads -- no launch in front of or behind node_kernel.
-template <bool PR, int WAVES, bool LP, bool HIST, int MD = PEDN_MAX_DEGREE, bool LU = false, bool TF = false>
-__global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
-  // dynamic LDS, sized by the host for the fullest block (pedn_create: node_lds): a block of nodes of degree 3..4 needs 24 of
-  // the 64 tiles a single degree-8 node would
-  extern __shared__ double pedn_lds[];
+// node_step: one step of one workgroup (bx = replica group, by = bin of nodes); node_kernel = one step per launch, node_persist_kernel
+// = a range of steps per launch (below).
+template <bool PR, bool LP, bool HIST, int MD, bool LU, bool TF>
+__device__ __forceinline__ void node_step(const DevView& v, const int t, const int bx, const int by, double* const pedn_lds) {
   double* const sR = pedn_lds;                          // [8][64] receiving flow of each wave's outgoing link
   double* const sS = pedn_lds + 8 * 64;                 // [8][64] LP only: sending flow of each wave's incoming link
   double* const sPS = pedn_lds + (LP ? 16 : 8) * 64;    // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = (int)(threadIdx.x & 63);
   const int RS = v.RS, L = v.L, Lall = v.Lall;
-  // blockIdx.x = replica group (fastest in dispatch order): blocks launched together touch neighbouring 512-byte chunks
-  // of the same history rows
-  const int r0 = v.sub0 + (int)blockIdx.x * 64;
+  const int r0 = v.sub0 + bx * 64;
   const int r = r0 + lane;
   const int tp = t - 1;
 #ifdef PEDN_PHASE_PROFILE
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   PH(0, lane);
 #endif
-  const SlotRec& W = v.slot_rec[(size_t)blockIdx.y * 8 + wave];  // wave-uniform: scalar loads
+  const SlotRec& W = v.slot_rec[(size_t)by * 8 + wave];  // wave-uniform: scalar loads
   const int node = W.node, slot = W.slot, base = W.base, m = W.m;
   const bool active = node >= 0;
   PH(1, lane + node);
@@ -1002,12 +999,82 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   PH(9, qo + qi);
   if (active && lane == 0) {
     for (int i = 1; i < 10; ++i) if (ph[i] == 0) ph[i] = ph[i - 1];
-    const size_t w = (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) % PEDN_PHASE_WAVES;
+    const size_t w = (((size_t)by * (size_t)(v.subRS / 64) + bx) * 8 + wave) % PEDN_PHASE_WAVES;
     for (int i = 1; i < 10; ++i) g_phase[w * 12 + i] += ph[i] - ph[i - 1];
     g_phase[w * 12 + 10] += 1ull;
     g_phase[w * 12 + 11] += ph[9] - ph[0];
   }
 #endif
+}
+
+template <bool PR, int WAVES, bool LP, bool HIST, int MD = PEDN_MAX_DEGREE, bool LU = false, bool TF = false>
+__global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
+  // dynamic LDS, sized by the host for the fullest block (pedn_create: node_lds): a block of nodes of degree 3..4 needs 24 of
+  // the 64 tiles a single degree-8 node would
+  // blockIdx.x = replica group (fastest in dispatch order): blocks launched together touch neighbouring 512-byte chunks
+  // of the same history rows
+  extern __shared__ double pedn_lds[];
+  node_step<PR, LP, HIST, MD, LU, TF>(v, t, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
+}
+
+// Persistent plan of small networks (pedn_run; network.py:266-287 for a RANGE of steps): steps [t0, t1) in ONE launch.  Replicas are
+// independent, and under the owner-wave / single-launch plan a step reads nothing that the same step writes -- so the n_bins workgroups
+// of a replica group only have to meet between steps.  They meet at a counter, and they all run on ONE XCD (workgroups go to the XCDs
+// round robin by their index: group g's workgroups have indices = g mod 8), so that what they exchange through the history rows never
+// has to leave that XCD's L2: before a workgroup arrives every wave has waited for the L2's acknowledgement of its stores (s_waitcnt
+// vmcnt(0) -- the vector L1 is write-through), after it leaves every wave drops its L1 (buffer_inv sc1; device memory is cached RW
+// in the L2 and is not touched by it).  No L2 write-back (what an agent-scope release would do: 17-80 us per round, round 3).
+// The placement is CHECKED: the first workgroup of a group publishes its XCC id, any other that finds a different one raises
+// PEDN_F_PLACEMENT for the group's replicas (results invalid).  A workgroup that waits longer than ~1 s raises the same flag and leaves:
+// every wave reaches the end of the kernel whatever happens.
+// MEASURED NEGATIVE (profiles/r04_persistent_step.txt), hence opt-in (PEDN_PERSIST=1): a step of a small network is the serial
+// chain of ONE wave (its row of fractions, its dependent loads, its binomials: 13 of nine_intersections' 16 us), not the launch gap --
+// the meeting alone costs 1.5-2.5 us per step, the L1 invalidate another 0.7-1.5 (it is needed: tools/l1_inv_probe.hip shows a stale
+// line surviving `buffer_inv sc0`; only sc1 drops it), and a launch per step is 16.2 us against 16.8 here.
+// -DPEDN_PERSIST_EXP=1: without the invalidate, =2: the meeting alone -- TIMING ONLY, the numbers are wrong.
+// bar: per replica group 32 words (one 128-byte line): [0] arrivals (monotonic over launches: `base` = its value before this one),
+// [1] XCC id of the group (0xffffffff before the first launch).
+template <bool PR, int WAVES, bool HIST, int MD, bool TF>
+__global__ __launch_bounds__(512, WAVES) void node_persist_kernel(DevView v, int t0, int t1, unsigned* bar, unsigned base, int n_bins, int rgroups) {
+  extern __shared__ double pedn_lds[];
+  __shared__ int s_dead;
+  const unsigned q = blockIdx.x >> 3;
+  const int by = (int)(q % (unsigned)n_bins);
+  const int bx = (int)(q / (unsigned)n_bins) * 8 + (int)(blockIdx.x & 7u);
+  if (bx >= rgroups) return;   // workgroup-uniform: the padding of the last eight groups
+  unsigned* const cnt = bar + (size_t)bx * 32;
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    const unsigned seen = atomicCAS(&cnt[1], 0xffffffffu, xcc);
+    s_dead = (seen != 0xffffffffu && seen != xcc) ? 1 : 0;
+  }
+  for (int t = t0; t < t1; ++t) {
+#if !defined(PEDN_PERSIST_EXP) || PEDN_PERSIST_EXP != 2
+    node_step<PR, false, HIST, MD, true, TF>(v, t, bx, by, pedn_lds);
+#endif
+    if (t + 1 == t1) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are in the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a misplaced workgroup still arrives: the others do not wait for it)
+      const unsigned target = base + (unsigned)n_bins * (unsigned)(t - t0 + 1);
+      int spins = 0;
+      while (!s_dead && (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 21)) { s_dead = 1; break; }
+      }
+    }
+    __syncthreads();
+    if (s_dead) {   // workgroup-uniform
+      if (threadIdx.x < 64 && bx * 64 + (int)threadIdx.x < v.RS) atomicOr(&v.flags[bx * 64 + threadIdx.x], PEDN_F_PLACEMENT);
+      return;
+    }
+#if !defined(PEDN_PERSIST_EXP) || PEDN_PERSIST_EXP != 1
+    asm volatile("buffer_inv sc1" ::: "memory");       // nothing stale in this CU's L1
+#endif
+  }
 }
 
 __device__ __forceinline__ double2 ld2(const double* p, size_t i) { return *reinterpret_cast<const double2*>(p + i); }

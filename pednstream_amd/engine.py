@@ -18,7 +18,8 @@ ERROR_BITS = {1: "negative sending flow (ValueError, link.py:345-346,365-366)",
               4: "history index out of range (IndexError)",
               8: "binomial with n < 0 (ValueError, link.py:382)",
               16: "zero-step look-back: result depends on node iteration order in the reference",
-              32: "node LP (assign_flows_type 'optimal') did not terminate"}
+              32: "node LP (assign_flows_type 'optimal') did not terminate",
+              64: "persistent plan: a replica group's workgroups did not share an XCD or did not all arrive (opt-in plan, PEDN_PERSIST=1)"}
 
 _I32P, _F64P, _F32P = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float)
 
@@ -433,10 +434,10 @@ class Engine:
 
     def plan_info(self):
         """The launch plan of run(): chains, owner-wave link update, and the result of the stream-overlap probe (include/pedn.h)."""
-        info = np.zeros(4, dtype=np.int32)
-        self._ck(self._lib.pedn_plan_info(self._h, info.ctypes.data_as(_I32P), 4))
+        info = np.zeros(5, dtype=np.int32)
+        self._ck(self._lib.pedn_plan_info(self._h, info.ctypes.data_as(_I32P), 5))
         return {"chains": int(info[0]), "link_update_by_next_node_kernel": bool(info[1]), "stream_probe_attempts": int(info[2]),
-                "stream_probe_us": int(info[3])}
+                "stream_probe_us": int(info[3]), "persistent_ranges": bool(info[4])}
 
     def set_streams(self, n):
         """Launch plan of run() for long ranges: 1 chain of launches, or 2 / 4 (the halves / quarters of the replica batch on as many

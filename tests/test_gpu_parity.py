@@ -276,6 +276,38 @@ def test_repeated_step_after_imposed_fractions_recomputes_them_under_every_plan(
         assert np.array_equal(ref[f], got[f]), f
 
 
+@pytest.mark.parametrize("name,R,steps", [("nine_intersections", 256, 120), ("long_corridor", 64, 150), ("od_flow_example", 3, 100)])
+def test_persistent_plan_gives_identical_histories(name, R, steps, monkeypatch):
+    """PEDN_PERSIST=1 (opt-in; a measured negative, profiles/r04_persistent_step.txt): ranges of pedn_run as ONE launch, the workgroups
+    of a replica group meeting between steps inside one XCD.  Long and short ranges, a single step in between, a lazy reset and a second
+    episode: every field and flag as with a launch per step; the placement check must not fire."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    def history(persist):
+        monkeypatch.setenv("PEDN_PERSIST", persist)
+        np.random.seed(7)
+        net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=R, rng_seed=11)
+        e = net.engine()
+        assert e.plan_info()["persistent_ranges"] == (persist == "1")
+        net.run(1, steps, check=False)
+        first = {f: e.read_block(LINK_FIELDS[f][0], 0, steps) for f in ALL_FIELDS}
+        net.reset(lazy=True)
+        net.run(1, 4, check=False); net.network_loading(4); net.run(5, 9, check=False); net.run(9, steps - 2, check=False)
+        net.run(steps - 2, steps, check=False)
+        rc, flags = e.error_flags()
+        out = (first, {f: e.read_block(LINK_FIELDS[f][0], 0, steps) for f in ALL_FIELDS}, flags.copy())
+        net.close()
+        return out
+
+    ref, got = history("0"), history("1")
+    assert not (got[2] & 64).any()
+    assert np.array_equal(ref[2], got[2])
+    for k in (0, 1):
+        for f in ALL_FIELDS:
+            assert np.array_equal(ref[k][f], got[k][f]), (k, f)
+
+
 @pytest.mark.parametrize("name,steps,owner", [("melbourne", 50, "1"), ("nine_intersections", 90, "0"), ("delft", 30, "0")])
 def test_four_chain_plan_gives_identical_histories(name, steps, owner, monkeypatch):
     """PEDN_STREAMS=4: the quarters of the batch as four chains of launches on four streams (pedn_set_streams(4)).  Whether the runtime
