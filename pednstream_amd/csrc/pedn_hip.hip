@@ -39,6 +39,7 @@ struct pedn_sim {
   // per SIMD: the slot waves of node_kernel<LU, TF> compute their own rows, a step is one launch.
   bool inline_tf_ok = false;
   int inline_tf = 0;
+  int inline_help = 0;      // ... with helper waves: node_kernel_h, sixteen waves per workgroup (PEDN_INLINE_TF=2)
   size_t node_lds_tf = 0;   // dynamic LDS of node_kernel<.., TF>
   std::vector<int32_t> h_slot_trow;
   int rl_chains = 0;   // pedn_rl_step steps the two halves of the envs as two chains that stay forked ACROSS calls (PEDN_RL_CHAINS)
@@ -940,8 +941,24 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       }
       (void)hipGetLastError();
     }
-    s->inline_tf = inl_possible && (size_t)(v.RS / 64) * (size_t)s->n_blocks <= 256;
-    if (const char* f = getenv("PEDN_INLINE_TF")) s->inline_tf = atoi(f) != 0 && inl_possible;
+    // ... by HELPER waves (node_kernel_h: sixteen waves per workgroup at 128 VGPRs, still one workgroup per CU): the row (~5 us) and the
+    // slot wave's own chain (~5 us) side by side -- nine_intersections x 256 16.2 -> 12.5 us per step, 45_intersections x 1024 (272
+    // workgroups) 17.9 -> 13.6; at 544 workgroups (x 2048) two launches per step are faster again (22.9 against 23.7).  The default
+    // up to 320 workgroups; PEDN_INLINE_TF=0 two launches, 1 the slot waves' own rows, 2 helper waves (forced whatever the grid).
+    s->inline_tf = inl_possible && (size_t)(v.RS / 64) * (size_t)s->n_blocks <= 320;
+    s->inline_help = s->inline_tf;
+    if (const char* f = getenv("PEDN_INLINE_TF")) { s->inline_tf = atoi(f) != 0 && inl_possible; s->inline_help = atoi(f) == 2 && inl_possible; }
+    if (s->inline_help && s->node_lds_tf > 64 * 1024) {
+      for (int pr = 0; pr < 2; ++pr) {
+        DevView& vv = s->v;
+        const int keep = vv.pr;
+        vv.pr = pr;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(node_kernel_for(s, true, true)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->node_lds_tf) != hipSuccess)
+          s->inline_help = 0;
+        vv.pr = keep;
+      }
+      (void)hipGetLastError();
+    }
     if (s->inline_tf) s->link_owner = 1;
     if (const char* f = getenv("PEDN_RL_OWNER")) s->rl_owner = atoi(f) != 0;
     // 0 = by batch: two chains where the step is not a pure chain of latencies any more -- from 4096 envs, and from 1024 with per-env
@@ -1358,6 +1375,10 @@ static node_kernel_fn node_kernel_for(const pedn_sim* s, bool lu, bool tf) {
 #define PEDN_NK(PR_, W_, LP_, LU_) (h ? (d6 ? node_kernel<PR_, W_, LP_, true, 6, LU_> : node_kernel<PR_, W_, LP_, true, 8, LU_>) \
                                       : (d6 ? node_kernel<PR_, W_, LP_, false, 6, LU_> : node_kernel<PR_, W_, LP_, false, 8, LU_>))
   if (s->node_lp) return s->v.pr ? PEDN_NK(true, 6, true, false) : PEDN_NK(false, 6, true, false);   // at 8 waves the LP instantiations spill 4..14 vector registers
+  if (lu && tf && s->inline_help) {   // helper waves compute the rows: sixteen waves per workgroup
+    if (s->v.pr) return h ? (d6 ? node_kernel_h<true, true, 6> : node_kernel_h<true, true, 8>) : (d6 ? node_kernel_h<true, false, 6> : node_kernel_h<true, false, 8>);
+    return h ? (d6 ? node_kernel_h<false, true, 6> : node_kernel_h<false, true, 8>) : (d6 ? node_kernel_h<false, false, 6> : node_kernel_h<false, false, 8>);
+  }
   if (lu && tf) {   // the slot waves compute their own rows of turning fractions: 2 waves per SIMD (at 4 -- 128 VGPRs -- 59 vector spills)
 #define PEDN_NKT(PR_) (h ? (d6 ? node_kernel<PR_, 2, false, true, 6, true, true> : node_kernel<PR_, 2, false, true, 8, true, true>) \
                          : (d6 ? node_kernel<PR_, 2, false, false, 6, true, true> : node_kernel<PR_, 2, false, false, 8, true, true>))
@@ -1464,7 +1485,7 @@ static void prewarm_chains(pedn_sim* s) {
   for (int c = 0; c < s->chains; ++c) {
     hipStream_t st = chain_stream(s, c);
     for (int lu = 0; lu < 2; ++lu) hipLaunchKernelGGL(node_kernel_for(s, lu != 0, false), dim3(1, 1), dim3(512), s->node_lds, st, v, 2);
-    if (s->inline_tf) hipLaunchKernelGGL(node_kernel_for(s, true, true), dim3(1, 1), dim3(512), s->node_lds_tf, st, v, 2);
+    if (s->inline_tf) hipLaunchKernelGGL(node_kernel_for(s, true, true), dim3(1, 1), dim3(s->inline_help ? 1024 : 512), s->node_lds_tf, st, v, 2);
     if (vl.hist) { hipLaunchKernelGGL((link_turn_kernel<false, false, 1, true>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
                    hipLaunchKernelGGL((link_kernel_1r<false, true>), dim3(1), dim3(256), 0, st, vl, 1); }
     else { hipLaunchKernelGGL((link_turn_kernel<false, false, 1, false>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
@@ -1512,8 +1533,9 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     s->tp_ran = 1;
   }
   const size_t nlds = inl ? s->node_lds_tf : s->node_lds;
-  if (ev) hipExtLaunchKernelGGL(node_kernel_for(s, lu, inl), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), nlds, stream, ev[2], ev[3], 0, vn, t);
-  else hipLaunchKernelGGL(node_kernel_for(s, lu, inl), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), nlds, stream, vn, t);
+  const dim3 nblock(inl && s->inline_help ? 1024 : 512);   // helper waves: sixteen per workgroup
+  if (ev) hipExtLaunchKernelGGL(node_kernel_for(s, lu, inl), dim3(rgroups, (unsigned)s->n_blocks), nblock, nlds, stream, ev[2], ev[3], 0, vn, t);
+  else hipLaunchKernelGGL(node_kernel_for(s, lu, inl), dim3(rgroups, (unsigned)s->n_blocks), nblock, nlds, stream, vn, t);
   if (inl && last_chain(s, half)) s->tp_ready = t;   // the fractions of t are in tfd[t & 1] (a following step that cannot inline computes its own)
   // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
   const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0 && !obs_fused) ? 2 : 1;   // (the diagnostic NS = 2 has no OBS instantiation)

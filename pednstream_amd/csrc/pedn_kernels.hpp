@@ -731,12 +731,17 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // launch of step t-1 would have used), right behind its batch of loads -- no launch in front of or behind node_kernel.
 // node_step: one step of one workgroup (bx = replica group, by = bin of nodes); node_kernel = one step per launch, node_persist_kernel
 // = a range of steps per launch (below).
-template <bool PR, bool LP, bool HIST, int MD, bool LU, bool TF>
+// HELP (with TF; node_kernel_h, workgroups of SIXTEEN waves): waves 8..15 are helpers -- helper 8 + k computes the row of fractions of
+// slot wave k (where that wave would compute its own) while the slot wave does its loads, link update and flows; they meet once, right
+// before the slot wave multiplies its row into the sending flow.  A step of a small batch is as long as its slowest wave's chain: the
+// row (~5 us) and the rest (~5 us) side by side instead of in a row.
+template <bool PR, bool LP, bool HIST, int MD, bool LU, bool TF, bool HELP = false>
 __device__ __forceinline__ void node_step(const DevView& v, const int t, const int bx, const int by, double* const pedn_lds) {
   double* const sR = pedn_lds;                          // [8][64] receiving flow of each wave's outgoing link
   double* const sS = pedn_lds + 8 * 64;                 // [8][64] LP only: sending flow of each wave's incoming link
   double* const sPS = pedn_lds + (LP ? 16 : 8) * 64;    // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave16 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int wave = HELP ? (wave16 & 7) : wave16;
   const int lane = (int)(threadIdx.x & 63);
   const int RS = v.RS, L = v.L, Lall = v.Lall;
   const int r0 = v.sub0 + bx * 64;
@@ -754,6 +759,16 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
   double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0, co_prev = 0.0, ci_prev = 0.0;
   int lin = 0, lout = 0, kind = 0;
   double tfr[MD - 1];
+
+  if (HELP && wave16 >= 8) {   // wave-uniform
+    if (active && W.kind == 1 && W.dyn == 1 && W.trow >= 0) {
+      const int* rw = v.trow_words + (size_t)W.trow * PEDN_TROW_WORDS;
+      const int tw0 = rw[lane], tw1 = rw[64 + lane];
+      turn_frac_body<PR, true, HIST, true>(v, t, 0u, pedn_lds + v.tf_lds_off + wave * PEDN_TF_INL_LDS, W.trow, r0, tw0, tw1);
+    }
+    __syncthreads();   // the meeting with the slot waves (below); the helpers are done
+    return;
+  }
 
   if (active) {
     kind = W.kind;
@@ -819,12 +834,12 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
       x.sepw_out = Pout.sep ? v.sepw[(size_t)lout * RS + r] : 0.0;
     };
     int tw0 = 0, tw1 = 0;
-    if (inl_row) {   // the row's record: one vector load per half, in flight with the batch below
+    if (inl_row && !HELP) {   // the row's record: one vector load per half, in flight with the batch below
       const int* rw = v.trow_words + (size_t)W.trow * PEDN_TROW_WORDS;
       tw0 = rw[lane]; tw1 = rw[64 + lane];
     }
     if (TF && lin < L) load_batch();
-    if (inl_row) turn_frac_body<PR, true, HIST, true>(v, t, 0u, my_tf, W.trow, r0, tw0, tw1);
+    if (inl_row && !HELP) turn_frac_body<PR, true, HIST, true>(v, t, 0u, my_tf, W.trow, r0, tw0, tw1);
     if (lin >= L) {  // virtual pair: origin demand in, unlimited sink out (node.py:176,186)
       s_i = v.demand[((size_t)W.demand_row * v.T1 + tp) * RS + r];
       co_prev = rowp(v.f64[F_CO], R64(F_CO, tp), lin, Lall, RS, r0)[lane];
@@ -833,7 +848,7 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
         if (inl_row) {
 #pragma unroll
           for (int jj = 0; jj < MD - 1; ++jj)
-            if (jj < m - 1) tfr[jj] = my_tf[(PEDN_TF_INL_ROWS + jj) * 64 + lane];
+            if (!HELP && jj < m - 1) tfr[jj] = my_tf[(PEDN_TF_INL_ROWS + jj) * 64 + lane];
         } else {
 #pragma unroll
           for (int jj = 0; jj < MD - 1; ++jj)
@@ -862,7 +877,7 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
         if (inl_row) {
 #pragma unroll
           for (int jj = 0; jj < MD - 1; ++jj)
-            if (jj < m - 1) tfr[jj] = my_tf[(PEDN_TF_INL_ROWS + jj) * 64 + lane];
+            if (!HELP && jj < m - 1) tfr[jj] = my_tf[(PEDN_TF_INL_ROWS + jj) * 64 + lane];
         } else {
 #pragma unroll
           for (int jj = 0; jj < MD - 1; ++jj)
@@ -913,6 +928,14 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
     }
     if (s_i < 0.0 || r_i < 0.0) fl |= PEDN_F_NEG_FLOW;
 
+    if (HELP) {   // the helper wave's row is in this wave's LDS rows once both have been here
+      __syncthreads();
+      if (inl_row) {
+#pragma unroll
+        for (int jj = 0; jj < MD - 1; ++jj)
+          if (jj < m - 1) tfr[jj] = my_tf[(PEDN_TF_INL_ROWS + jj) * 64 + lane];
+      }
+    }
     if (kind == 1) {
       // P[i][j] * s_i  (node.py:285)
 #pragma unroll
@@ -927,6 +950,8 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
     }
     sR[wave * 64 + lane] = r_i;
     if (LP) sS[wave * 64 + lane] = s_i;
+  } else if (HELP) {
+    __syncthreads();   // an idle slot wave meets the helpers too
   }
   PH(5, r_i);
   __syncthreads();
@@ -1015,6 +1040,13 @@ __global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
   // of the same history rows
   extern __shared__ double pedn_lds[];
   node_step<PR, LP, HIST, MD, LU, TF>(v, t, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
+}
+
+// the single-launch plan with helper waves (node_step<.., HELP>): sixteen waves per workgroup, 128 vector registers each
+template <bool PR, bool HIST, int MD>
+__global__ __launch_bounds__(1024) void node_kernel_h(DevView v, int t) {
+  extern __shared__ double pedn_lds[];
+  node_step<PR, false, HIST, MD, true, true, true>(v, t, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
 }
 
 // Persistent plan of small networks (pedn_run; network.py:266-287 for a RANGE of steps): steps [t0, t1) in ONE launch.  Replicas are

@@ -185,7 +185,7 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
     from golden_util import DATA
 
     def history(fuse, waves, stepwise, general="0", lds_limit="64", md="6", link_ns="0", heavy="2", pairs_adj="1", owner="0", inline="0"):
-        monkeypatch.setenv("PEDN_INLINE_TF", inline)          # 1: the single-launch plan -- node_kernel<LU, TF>'s slot waves compute their own rows (where the model's rows allow)
+        monkeypatch.setenv("PEDN_INLINE_TF", inline)          # 1: the single-launch plan -- node_kernel<LU, TF>'s slot waves compute their own rows (where the model's rows allow); 2: helper waves do
         monkeypatch.setenv("PEDN_LINK_OWNER", owner)          # 1: pedn_run's owner-wave plan -- node_kernel<LU>(t + 1) performs the link update of t
         monkeypatch.setenv("PEDN_LU_WAVES", waves)
         monkeypatch.setenv("PEDN_PAIRS_ADJ", pairs_adj)        # 0: the link update takes its two link ids from the corridor's record (models whose
@@ -234,7 +234,10 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
                     ("1", "8", True, "0", "64", "6", "0", "2", "1", "1"), ("0", "6", True, "0", "64", "8", "0", "2", "1", "1"),
                     # the single-launch plan: ranges, single steps, step by step with setters and a reset
                     ("1", "8", False, "0", "64", "6", "0", "2", "1", "1", "1"), ("1", "8", True, "0", "64", "6", "0", "2", "1", "1", "1"),
-                    ("0", "8", False, "0", "64", "8", "0", "2", "0", "1", "1")):
+                    ("0", "8", False, "0", "64", "8", "0", "2", "0", "1", "1"),
+                    # ... with helper waves (node_kernel_h: sixteen waves per workgroup, the second eight compute the rows)
+                    ("1", "8", False, "0", "64", "6", "0", "2", "1", "1", "2"), ("1", "8", True, "0", "64", "6", "0", "2", "1", "1", "2"),
+                    ("0", "8", False, "3", "1", "8", "0", "2", "0", "1", "2")):
         got = history(*variant)
         for f in ALL_FIELDS:
             assert np.array_equal(ref[f], got[f]), (variant, f)

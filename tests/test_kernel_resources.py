@@ -58,6 +58,8 @@ BUDGETS = {
     r"node_kernel<true, 6, false, (true|false), 6, true, false>": (80, None, False),
     # the single-launch plan of small batches (the slot waves compute their own rows of turning fractions): one block per CU, no scratch
     r"node_kernel<(true|false), 2, false, (true|false), \d, true, true>": (256, None, True),
+    # ... with helper waves: sixteen waves per workgroup = 4 per SIMD, no scratch
+    r"node_kernel_h<(true|false), (true|false), \d>": (128, None, True),
     # networks with a node of 7 or 8 corridors (loops unrolled for 8): launched at 6 waves per SIMD (pedn_create: node_waves)
     r"node_kernel<false, 6, false, (true|false), 8, false, false>": (80, None, True),
     # per-replica link parameters (randomised RL resets, ensembles): launched at 6 waves per SIMD (pedn_create: node_waves_pr) --
