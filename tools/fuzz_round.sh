@@ -36,9 +36,12 @@ part_b() {
   PEDN_LINK_OWNER=1 PEDN_NODE_MD=8 python3 -u tools/gpu_fuzz.py $((S+4100*K)) $((S+4200*K))
   PEDN_LINK_OWNER=0 python3 -u tools/gpu_fuzz.py $((S+4200*K)) $((S+4400*K))
   PEDN_LINK_OWNER=1 python3 -u tools/gpu_fuzz_chains.py $((S+4400*K)) $((S+4500*K))
-  echo "# the single-launch plan of small batches (node_kernel<LU, TF>: the slot waves compute their own rows of turning fractions) is the"
-  echo "# default for these 3-replica networks wherever their rows allow it, i.e. in every campaign above; here forced OFF:"
+  echo "# the single-launch plan of small batches with HELPER waves (node_kernel_h: waves 8..15 of a workgroup compute the rows of turning"
+  echo "# fractions of slot waves 0..7) is the default for these 3-replica networks wherever their rows allow it, i.e. in every campaign"
+  echo "# above; here forced OFF, and with the slot waves computing their own rows (node_kernel<LU, TF>, PEDN_INLINE_TF=1):"
   PEDN_INLINE_TF=0 python3 -u tools/gpu_fuzz.py $((S+4500*K)) $((S+4800*K))
+  PEDN_INLINE_TF=1 python3 -u tools/gpu_fuzz.py $((S+4800*K)) $((S+5000*K))
+  PEDN_INLINE_TF=1 python3 -u tools/gpu_fuzz.py $((S+5600*K)) $((S+5700*K)) scenarios
   echo "# lazy reset against the ordinary reset under random sequences of calls (tools/gpu_fuzz_lazy.py):"
   python3 -u tools/gpu_fuzz_lazy.py $((S+5000*K)) $((S+5200*K))
   echo "# the engine's own launch plans against two launches per step on one stream under random sequences of calls (tools/gpu_fuzz_plans.py):"
