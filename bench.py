@@ -738,7 +738,7 @@ def main():
             # where the env step stops being latency-bound: more envs per launch (recent-history mode: 8192 envs are 16 GB)
             "by_n_envs_recent_history": {str(n): {k: v for k, v in measure_rl("45_intersections", n, args.steps, args.warmup, "recent", randomized=False).items()
                                                   if k in ("value", "unit", "device_ms_per_step", "whole_step_frac", "steps")}
-                                         for n in (2048, 4096, 8192)},
+                                         for n in (1024, 2048, 4096, 8192)},   # 1024 envs: the single-launch plan with helper waves + the observations
             # a policy in the loop (torch on the same GPU): what a rollout sees end to end
             "end_to_end_random_torch_policy": rl_end_to_end("45_intersections", 2048),
             # whole episodes WITH their resets (rl/pz_pednet_env.py:143-193 resets every episode)

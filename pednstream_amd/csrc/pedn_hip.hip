@@ -943,9 +943,11 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     }
     // ... by HELPER waves (node_kernel_h: sixteen waves per workgroup at 128 VGPRs, still one workgroup per CU): the row (~5 us) and the
     // slot wave's own chain (~5 us) side by side -- nine_intersections x 256 16.2 -> 12.5 us per step, 45_intersections x 1024 (272
-    // workgroups) 17.9 -> 13.6; at 544 workgroups (x 2048) two launches per step are faster again (22.9 against 23.7).  The default
-    // up to 320 workgroups; PEDN_INLINE_TF=0 two launches, 1 the slot waves' own rows, 2 helper waves (forced whatever the grid).
-    s->inline_tf = inl_possible && (size_t)(v.RS / 64) * (size_t)s->n_blocks <= 320;
+    // workgroups) 17.9 -> 13.6, x 1280 (340) 20.4 -> 14.7 under pedn_run's two chains and 20.5 -> 19.1 step by step; x 1536 (408) still
+    // wins under pedn_run (21.3 -> 17.5) but not step by step (22.3 -> 23.1), at 544 (x 2048) two launches per step are faster either
+    // way (22.9 against 23.7).  The default up to 352 workgroups; PEDN_INLINE_TF=0 two launches, 1 the slot waves' own rows, 2 helper
+    // waves (forced whatever the grid).  profiles/r04_inline_helpers.txt
+    s->inline_tf = inl_possible && (size_t)(v.RS / 64) * (size_t)s->n_blocks <= 352;
     s->inline_help = s->inline_tf;
     if (const char* f = getenv("PEDN_INLINE_TF")) { s->inline_tf = atoi(f) != 0 && inl_possible; s->inline_help = atoi(f) == 2 && inl_possible; }
     if (s->inline_help && s->node_lds_tf > 64 * 1024) {
