@@ -21,3 +21,11 @@ def test_example_runs(script, args, expect, tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert expect in out.stdout, out.stdout[-1000:]
+
+
+def test_graft_entry_smoke_passes_under_the_default_plans():
+    """__graft_entry__.smoke() as the driver runs it (a process of its own): it asserts which launch plan each of its models takes,
+    and went stale once when a new default plan arrived -- it runs with the suite now."""
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "smoke ok" in out.stdout, out.stdout[-1000:]
