@@ -2252,7 +2252,10 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
     const bool last = k == action_gap - 1;
     bool observed = false;
     // owner-wave plan of the RL step (rl_owner): only with the actions folded into node_kernel and the observations in the second launch
-    const bool lazy = !two && (s->rl_owner || s->inline_tf) && s->rl_fold && s->fuse_obs && (!actions || fold != nullptr);
+    // (NOT with the single-launch plan of small batches: the observations are a second launch either way, and with the rows of t + 1 riding
+    // in it the two launches are shorter -- 45_intersections x 256 envs 17.5 us per env step against 24.8, where every other step also
+    // fell back to stand-alone fractions because the actions could not be folded; profiles/r04_rl_small_batches.txt)
+    const bool lazy = !two && s->rl_owner && s->rl_fold && s->fuse_obs && (!actions || fold != nullptr);
     if (two) {
       s->run_chains = 2;
       for (int c = 0; c < 2; ++c) launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, c, false);
