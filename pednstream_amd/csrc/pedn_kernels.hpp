@@ -519,9 +519,16 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
     // the record behind the row's last group belongs to another row: size 0, evaluated on harmless values, nothing stored
     const int na = rdl(gcur, 0), nb = 2 * pi + 1 < n_grp ? rdl(gcur, 32) : 0;
     const int nmax = max(na, nb);
+    // -DPEDN_LT_LEAN (diagnostic build, with -DPEDN_TF_LDS_ROWS=40): ONE softmax group at a time and link_turn_kernel held to 6 waves per
+    // SIMD -- 80 VGPRs (84-100 B of scratch), 24 KB of LDS, six workgroups per CU.  Measured: delft x 1024 two chains
+    // 43.4 -> 49.5 us per step, one chain 49.1 -> 51.7, RL step 25.3 -> 30.6 (profiles/r04_lean_link_turn.txt): the launch is as long as
+    // its longest rows' chains, which the side-by-side evaluation halves; more resident workgroups do not buy that back.
+#ifndef PEDN_LT_LEAN
     if (nmax <= 2 && !(v.tf_general & 1)) eval_pair(std::integral_constant<int, 2>{}, gcur, na, nb);
     else if (nmax <= 3 && !(v.tf_general & 1)) eval_pair(std::integral_constant<int, 3>{}, gcur, na, nb);
-    else { eval_slow(gcur, 0, na); eval_slow(gcur, 32, nb); }
+    else
+#endif
+    { (void)nmax; eval_slow(gcur, 0, na); eval_slow(gcur, 32, nb); }
     gcur = gnext;
   }
   TPH(2, lane);
@@ -1431,7 +1438,13 @@ __global__ __launch_bounds__(256) void rl_observe_kernel(DevView v, RlView q, in
 // the short rows had finished and ended long after the long rows (delft x 1024: 20.8 us for 12 us of critical path).
 // (OBS = false: the instantiation ordinary stepping uses carries neither the LDS nor the registers of the third part)
 template <bool PR, bool OBS, int NS, bool HIST>
-__global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, unsigned n_tp_heavy, RlView q,
+__global__
+#ifdef PEDN_LT_LEAN
+__launch_bounds__(256, 6)
+#else
+__launch_bounds__(256, 4)
+#endif
+void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, unsigned n_tp_heavy, RlView q,
                                                            int accumulate) {
   // one LDS buffer for whichever part this workgroup is (the observation part needs 6 KB of the turning fractions' 35.5 KB)
   __shared__ double lds[PEDN_TF_LDS_DOUBLES];
