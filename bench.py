@@ -135,6 +135,7 @@ def cpu_baseline(model, net, origin_nodes, network, seconds_target=7.0, demand_s
     alln, na, sa, ta = _oracle_rate(model, net, origin_nodes, usable, seconds_target, key0=10000, demand_scale=demand_scale)
     ex_bytes, ex_detail = executed_bytes(t1 + ta)
     out = {"value": alln, "unit": "link-updates/s", "cores": usable, "kind": "port",
+           "sample_short": f"{na} replicas x {T - 1} steps of {network}, {usable} threads, {sa:.1f} s; 1 thread: {n1} replicas, {s1:.1f} s",
            "sample": f"{na} replicas x {T - 1} steps of {network} on {usable} host threads ({sa:.1f} s) and {n1} replicas on 1 thread "
                      f"({s1:.1f} s); oracle/pedn_oracle.c, one replica per thread, same per-replica demand and RNG keys as the GPU run",
            "one_thread": one, "all_cores": alln, "cores_total": cores, "cores_usable": usable, "cpu_model": cpu_model_name(),
@@ -556,7 +557,10 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
     # duration (`basis_kind`).  What the memory side MOVED for the launch (FETCH_SIZE + WRITE_SIZE) rides beside it as `traffic` /
     # `frac_counter` (null without counter passes, live or committed), and the contract's bytes on executed paths as `frac_executed`
     # (filled in from cpu_baseline's tallies).
-    achieved = achieved_alg
+    # `frac` / `achieved` are on the bytes the memory side MOVED whenever this run's own counter passes exist (`basis_kind`: "moved" --
+    # the figure the memory system can be held to); without counters they are the contract's bytes ("algorithmic").  Both always ride
+    # along as frac_counter / frac_algorithmic, and the contract's bytes on executed paths as frac_executed.
+    achieved = achieved_alg if not live else traffic * chains / (node_busy_ms * 1e-3) / 1e9
     if owner:
         traffic2 = 0.0               # one launch per step: the range's single trailing link_kernel is not part of a step's working set
     working_set = None if traffic is None or traffic2 is None else (traffic + traffic2) * chains
@@ -568,14 +572,16 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
         "higher_is_better": True, "scaling": "strong" if args.total_replicas else "weak", "vs_baseline": None, "dtype": "f64+f32", "data": "synthetic",
         "config": {"workload": f"{network} network ({L} links, {len(net.nodes)} nodes, T={T}) x {R} replicas per GPU, "
                                f"{'full-record' if args.history == 'full' else 'recent-history'} mode, per-replica Poisson demand and Philox keys",
+                   "network": network, "history": "full-record" if args.history == "full" else "recent",
                    "replicas_per_gpu": R, "replicas_total": R * world, "links": L,
                    "parallelism": f"replica-sharded x{world}, no step-path collective"},
         "device_ms_per_step": dev_ms / args.steps,
         "roofline": {"bound": "hbm",
                      "kernel": ("node_kernel<LU>: sending / receiving flows, node model, cumulative counts AND the link update of the previous step "
                                 "(one launch per step)" if owner else "node_kernel: sending / receiving flows, node model, cumulative counts"),
+                     "kernel_name": "node_kernel<LU>" if owner else "node_kernel",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "basis_kind": "algorithmic",
+                     "basis_kind": "moved" if live else "algorithmic",
                      "basis": f"SURVEY 8(d) contract bytes of the kernel's launches of one step ({node_kernel_bytes} B per link-update x {L * R} "
                               "link-updates) / the kernel's share of the step's machine time = device time per step x (its mean launch duration / "
                               "the sum of the step's mean launch durations; dispatch timestamps, pedn_profile_timeline).  With one chain of launches "
@@ -617,6 +623,70 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
     if alt_plan is not None:
         out["two_chain_plan"] = alt_plan
     return out, net, origins
+
+
+def _sig(x, n=6):
+    """Floats to n significant digits (the compact line); everything else unchanged."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{n}g}")
+
+
+def _pick(d, keys):
+    return {k: _sig(d[k]) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
+
+
+def compact_line(out):
+    """The line the driver parses: the LAST line of stdout, < 4 KB, numbers and short identifiers only.  Everything measured (every
+    extra with its own roofline block, the prose that says how each figure was formed) is written to bench_full.json beside this script."""
+    rf, cb = out["roofline"], out.get("cpu_baseline")
+    cfg = out["config"]
+    line = {k: _sig(out[k]) for k in ("metric", "value", "unit", "n_gpus", "ranks_seen", "steps", "warmup", "ms_per_step", "device_ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in out}
+    line["config"] = {"workload": f"{cfg['network']} x {cfg['replicas_per_gpu']} replicas per GPU, {cfg['history']} histories",
+                      "replicas_per_gpu": cfg["replicas_per_gpu"], "replicas_total": cfg["replicas_total"], "links": cfg["links"],
+                      "parallelism": f"replicas x{out['n_gpus']}"}
+    r = _pick(rf, ("bound", "kernel_name", "achieved", "peak", "unit", "frac", "basis_kind", "traffic", "frac_algorithmic", "frac_counter",
+                   "frac_executed", "traffic_bytes_per_link_update", "algorithmic_bytes_per_link_update", "algorithmic_bytes_per_launch",
+                   "fits_infinity_cache", "concurrent_chains", "avg_launch_ms", "whole_step_frac", "whole_step_frac_counter"))
+    r["kernel"] = r.pop("kernel_name")
+    pl = rf.get("launch_plan") or {}
+    r["launch_plan"] = {k: pl[k] for k in ("chains", "link_update_by_next_node_kernel", "single_launch_step") if k in pl}
+    if "one_chain" in rf:
+        r["one_chain"] = _pick(rf["one_chain"], ("avg_launch_ms", "frac"))
+    line["roofline"] = r
+    if cb is not None:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "sample_short", "cpu_model", "one_thread", "all_cores"))
+        c["sample"] = c.pop("sample_short")
+        if "reference_python_equiv" in cb:
+            c["reference_python_equiv"] = {"one_core": _sig(cb["reference_python_equiv"]["one_core"])}
+        line["cpu_baseline"] = c
+    ex = out.get("extra")
+    if ex:
+        e2 = {}
+        for name, v in ex.items():
+            if "error" in v:
+                e2[name] = {"error": str(v["error"])[:80]}
+            elif name == "config5_rl_45int_x2048":
+                c5 = {"unit": "env-steps/s"}
+                for k in ("plain", "randomized"):
+                    if k in v:
+                        c5[k] = _pick(v[k], ("value", "ms_per_step", "whole_step_frac"))
+                if "by_n_envs_recent_history" in v:
+                    c5["by_n_envs"] = {n: _sig(x["value"], 4) for n, x in v["by_n_envs_recent_history"].items()}
+                for k in ("end_to_end_random_policy", "end_to_end_mlp_policy"):
+                    if k in v:
+                        c5[k] = {kk: _sig(x["value"], 4) for kk, x in v[k].items() if isinstance(x, dict) and "value" in x}
+                if "sustained" in v:
+                    c5["sustained"] = {kk: _sig(x["value"], 4) for kk, x in v["sustained"].items()}
+                e2[name] = c5
+            else:
+                e2[name] = _pick(v, ("value", "ms_per_step"))
+                if "roofline" in v:
+                    e2[name].update(_pick(v["roofline"], ("whole_step_frac", "whole_step_frac_counter")))
+        line["extra"] = e2
+    line["full"] = "bench_full.json"
+    return line
 
 
 def main():
@@ -745,7 +815,18 @@ def main():
             "sustained": {f"{mode}_{hist}": sustained_rl("45_intersections", 2048, hist, mode)
                           for hist in ("full", "recent") for mode in ("plain", "vectorised", "reference")}})
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # everything measured goes to a file beside the script; the LAST line of stdout is the compact headline object (< 4 KB)
+        try:
+            with open(os.path.join(ROOT, "bench_full.json"), "w") as f:
+                json.dump(out, f)
+        except OSError as exc:
+            print(f"bench.py: bench_full.json not written ({exc})", file=sys.stderr)
+        line = json.dumps(compact_line(out), separators=(",", ":"))
+        if len(line) >= 4096:                       # never let detail cost the line: drop the extras before anything else
+            slim = compact_line(out)
+            slim.pop("extra", None)
+            line = json.dumps(slim, separators=(",", ":"))
+        print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -114,6 +114,9 @@ def test_bench_under_the_launcher_runs_the_rccl_branch_once():
         assert out.returncode == 0, out.stderr[-3000:]
         rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
         assert len(rows) == 1, out.stdout[-2000:]
+        last = out.stdout.rstrip("\n").splitlines()[-1]
+        assert last.startswith("{") and len(last) < 4096, len(last)      # the driver parses the LAST line of an 8 KB stdout tail
+        assert rows[0]["roofline"]["frac"] > 0 and rows[0]["roofline"]["kernel"].startswith("node_kernel")
         return rows[0]
 
     launched = line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
