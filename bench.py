@@ -360,10 +360,13 @@ def sustained_rl(network, B, history, mode, episodes=3):
             "history": history, "reset": mode}
 
 
-def rl_end_to_end(network, B, steps=300):
-    """Config #5 with a policy in the loop: a random torch policy on the GPU whose actions depend on nothing but torch's generator, the
-    observations / rewards consumed by torch ops -- env-steps/s END TO END (host enqueue included), with step_device synchronising
-    the host every step and with the streams chained by events (sync=False)."""
+def rl_end_to_end(network, B, steps=600):
+    """Config #5 the way BASELINE words it -- the envs FEEDING a policy: policy forward -> env step -> reward bookkeeping per iteration,
+    everything on the GPU, env-steps/s END TO END (host enqueue included) over `steps` iterations of one episode.  Two policies: a
+    random one (one torch.rand per step) and a 3-layer MLP on the observations (float32, 64 hidden units).  Three ways of running the
+    loop: step_device synchronising the host every step; streams chained by events (sync=False); and the whole iteration captured once
+    as a torch.cuda.CUDAGraph and replayed (VecPedNetEnv.capture: the engine's device-resident step clock makes the env step's launches
+    constant)."""
     import torch
 
     from pednstream_amd.rl_env import VecPedNetEnv
@@ -371,25 +374,62 @@ def rl_end_to_end(network, B, steps=300):
     env = VecPedNetEnv(network, n_envs=B, obs_mode="option3", action_gap=1, seed=0, data_dir=os.path.join(ROOT, "data"), history="recent")
     low = torch.as_tensor(env.action_low, device="cuda", dtype=torch.float64)
     span = torch.as_tensor(env.action_high, device="cuda", dtype=torch.float64) - low
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    torch.manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(env.n_obs, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(),
+                              torch.nn.Linear(64, env.n_actions), torch.nn.Sigmoid()).to("cuda")
+    for p in mlp.parameters():
+        p.requires_grad_(False)
+
+    def random_policy(obs):
+        return low + span * torch.rand((B, env.n_actions), generator=gen, device="cuda", dtype=torch.float64)
+
+    def mlp_policy(obs):
+        return (low + span * mlp(obs).double()).contiguous()
+
+    ret = torch.zeros(B, device="cuda")
+
+    def on_step(obs, rew):
+        ret.add_(rew[:, 0])
+
+    K = min(steps, env.simulation_steps - 2)
     out = {}
-    for label, sync in (("host_synchronised_every_step", True), ("streams_chained_by_events", False)):
-        env.reset()
-        gen = torch.Generator(device="cuda").manual_seed(0)
-        ret = torch.zeros(B, device="cuda")
-        K = min(steps, env.simulation_steps - 1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            actions = low + span * torch.rand((B, env.n_actions), generator=gen, device="cuda", dtype=torch.float64)
-            obs, rew, _ = env.step_device(actions, sync=sync)
-            ret += rew[:, 0]
-        torch.cuda.synchronize()
-        out[label] = {"value": B * K / (time.perf_counter() - t0), "unit": "env-steps/s", "steps": K, "mean_return": float(ret.mean())}
+    for pname, policy in (("end_to_end_random_policy", random_policy), ("end_to_end_mlp_policy", mlp_policy)):
+        res = {}
+        for label in ("host_synchronised_every_step", "streams_chained_by_events", "graph_replay"):
+            env.reset()
+            ret.zero_()
+            obs = env.device_views()[0]
+            roll = env.capture(policy, on_step, generators=[gen]) if label == "graph_replay" else None
+            for _ in range(8):                        # warm-up inside the episode (the graph is captured here)
+                if roll is not None:
+                    roll.step()
+                else:
+                    o, r, _ = env.step_device(policy(obs), sync=label == "host_synchronised_every_step")
+                    on_step(o, r)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K - 8):
+                if roll is not None:
+                    roll.step()
+                else:
+                    o, r, _ = env.step_device(policy(obs), sync=label == "host_synchronised_every_step")
+                    on_step(o, r)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[label] = {"value": B * (K - 8) / dt, "unit": "env-steps/s", "steps": K - 8, "us_per_iteration": dt / (K - 8) * 1e6,
+                          "mean_return": float(ret.mean())}
+            if roll is not None:
+                res[label]["replays"], res[label]["eager_steps"] = roll.replays, roll.eager_steps
+        out[pname] = res
     env.close()
     return out
 
 
 def bench_rl(args):
+    if args.rl_end_to_end:
+        print(json.dumps(rl_end_to_end(args.network, args.replicas, args.steps)), flush=True)
+        return
     print(json.dumps(measure_rl(args.network, args.replicas, args.steps, args.warmup, args.history, args.randomize)), flush=True)
 
 
@@ -705,6 +745,7 @@ def main():
     ap.add_argument("--rng-mode", default="philox", choices=["philox", "meanfield"], help="diagnostic: meanfield removes the RNG work")
     ap.add_argument("--rl", action="store_true", help="config #5 instead: batched RL env step, env-steps/s")
     ap.add_argument("--randomize", action="store_true", help="with --rl: reset(options={'randomize': True}) first (per-replica scenarios)")
+    ap.add_argument("--rl-end-to-end", action="store_true", help="with --rl: the policy-in-the-loop measurement (eager / events / replayed graph) instead")
     ap.add_argument("--total-replicas", type=int, default=0, help="strong scaling: this many replicas in all, total / N per GPU "
                     "(BASELINE config #4: --total-replicas 4096; its weak-scaling shape is --replicas 512)")
     ap.add_argument("--history", default="full", choices=["full", "recent"], help="full: the reference's footprint (the headline mode); "
@@ -809,8 +850,8 @@ def main():
             "by_n_envs_recent_history": {str(n): {k: v for k, v in measure_rl("45_intersections", n, args.steps, args.warmup, "recent", randomized=False).items()
                                                   if k in ("value", "unit", "device_ms_per_step", "whole_step_frac", "steps")}
                                          for n in (1024, 2048, 4096, 8192)},   # 1024 envs: the single-launch plan with helper waves + the observations
-            # a policy in the loop (torch on the same GPU): what a rollout sees end to end
-            "end_to_end_random_torch_policy": rl_end_to_end("45_intersections", 2048),
+            # a policy in the loop (torch on the same GPU): what a rollout sees end to end, eager and as a replayed graph
+            **rl_end_to_end("45_intersections", 2048),
             # whole episodes WITH their resets (rl/pz_pednet_env.py:143-193 resets every episode)
             "sustained": {f"{mode}_{hist}": sustained_rl("45_intersections", 2048, hist, mode)
                           for hist in ("full", "recent") for mode in ("plain", "vectorised", "reference")}})

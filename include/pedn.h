@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PEDN_ABI_VERSION 3
+#define PEDN_ABI_VERSION 4
 #define PEDN_ALL (-1)
 #define PEDN_MAX_DEGREE 8 /* incident corridor slots per node handled by the node kernel */
 
@@ -53,8 +53,7 @@ extern "C" {
 #define PEDN_F_NEG_BINOM 8u   /* binomial with n < 0               (numpy ValueError at link.py:382) */
 #define PEDN_F_SAME_STEP 16u  /* look-back of 0 steps: the reference result depends on node iteration order */
 #define PEDN_F_LP 32u         /* node LP (assign_flows_type 'optimal') did not terminate: `res.success` false, node.py:267 */
-#define PEDN_F_PLACEMENT 64u  /* persistent plan of pedn_run: a replica group's workgroups were not placed on one XCD, or one of them
-                                 never arrived -- the numbers of these replicas are invalid (the plan is opt-in: PEDN_PERSIST=1) */
+/* (bit 64u is reserved: it belonged to the persistent plan of ABI 3, removed as a measured negative) */
 
 /* RNG modes (oracle/rng_contract.py) */
 #define PEDN_RNG_PHILOX 0
@@ -213,10 +212,18 @@ int pedn_read(pedn_sim* sim, int32_t field, int32_t t0, int32_t t1, int32_t link
 /* number of time indices field `field` keeps: T+1, or the size of its ring in PEDN_HIST_RECENT mode (time index t lives in
  * row t mod that size) */
 int pedn_history_rows(pedn_sim* sim, int32_t field);
+/* Everything the engine still owes the histories is enqueued on pedn_stream(): a link update left pending by the last pedn_step /
+ * pedn_run (the next step's node kernel would have performed it), chains that are still forked, the rows a lazy reset declared
+ * unwritten (cleared now).  Asynchronous.  After it, work ordered behind pedn_stream() sees every row of every field complete. */
+int pedn_flush(pedn_sim* sim);
 /* zero-copy access for on-device consumers: HBM base pointer of a history field laid out
- * [pedn_history_rows][columns][replica_stride]; columns/replica_stride may be NULL */
+ * [pedn_history_rows][columns][replica_stride]; columns/replica_stride may be NULL.  The call itself performs pedn_flush, so the
+ * view is complete for a consumer that orders itself behind pedn_stream() NOW.  The pointer stays valid for the handle's life, but
+ * what it shows is complete only up to the last pedn_flush / pedn_device_ptr / pedn_synchronize: after a later pedn_step / pedn_run
+ * (last step's density / speed / travel time / num_pedestrians rows pending) or pedn_reset_lazy (rows above the current step hold the
+ * previous episode) a consumer that kept the pointer calls pedn_flush before it orders itself behind the stream again. */
 void* pedn_device_ptr(pedn_sim* sim, int32_t field, int64_t* columns, int64_t* replica_stride);
-/* hipStream_t the engine launches on */
+/* hipStream_t the engine launches on (a pure getter: it enqueues nothing -- see pedn_flush) */
 void* pedn_stream(pedn_sim* sim);
 
 /* HIP-event timing on the engine's stream: begin records an event, end records + synchronises and returns the
@@ -239,18 +246,15 @@ int pedn_profile_run(pedn_sim* sim, int32_t t0, int32_t t1, float ms[3], int32_t
  * `capacity` rows (3 per step and chain), *n_rows of them written.  Shows how the launches of the two chains overlap. */
 int pedn_profile_timeline(pedn_sim* sim, int32_t t0, int32_t t1, float* out, int32_t capacity, int32_t* n_rows, int32_t* chains);
 
-/* launch plan of pedn_run for long ranges: 1 = one chain of launches on the engine's stream, 2 / 4 = the halves / quarters of the
- * replicas as that many chains on as many streams (2 is the default from 1024 replicas; replicas are independent, results are the
- * same).  The streams are probed to run side by side (pedn_plan_info); when the runtime cannot provide that many independent queues
- * the plan falls back to the number it can (4 chains want GPU_MAX_HW_QUEUES >= 5 in the environment before the HIP runtime starts). */
+/* launch plan of pedn_run for long ranges: 1 = one chain of launches on the engine's stream, 2 = the halves of the replicas as two
+ * chains on two streams (the default from 1024 replicas; replicas are independent, results are the same).  The two streams are probed
+ * to run side by side (pedn_plan_info); when the runtime cannot provide two independent queues the plan falls back to one chain. */
 int pedn_set_streams(pedn_sim* sim, int32_t n);
-/* The launch plan of pedn_run: info[0] = chains (1 | 2 | 4), info[1] = 1 when the link update is performed by the next step's node kernel
+/* The launch plan of pedn_run: info[0] = chains (1 | 2), info[1] = 1 when the link update is performed by the next step's node kernel
  * (one launch per step), info[2] = streams created until one was found that overlaps with the engine's stream (0: not probed yet;
  * the runtime may map two streams onto one hardware queue, which would serialise the chains), info[3] = duration in microseconds of
  * the probe's two concurrent 300 us kernels on the pair kept (~300: they overlap, ~600: they do not); n = entries of info (>= 4);
- * with n >= 5: info[4] = 1 when ranges of three and more steps run as ONE persistent launch (small networks in full-record mode: the
- * workgroups of a replica group meet between steps inside one XCD; opt-in with PEDN_PERSIST=1 -- measured no faster than a
- * launch per step --, PEDN_F_PLACEMENT). */
+ * with n >= 5: info[4] = 0 (reserved). */
 int pedn_plan_info(pedn_sim* sim, int32_t* info, int32_t n);
 
 /* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */
@@ -327,6 +331,26 @@ int pedn_rl_observe(pedn_sim* sim, int32_t t, int32_t accumulate, float* obs, fl
  * and the engine's with events instead of host synchronisation (VecPedNetEnv.step_device(sync=False)). */
 int pedn_rl_step(pedn_sim* sim, const double* actions, int32_t on_device, int32_t t, int32_t action_gap, float* obs,
                  float* rewards);
+/* ---- env steps with CONSTANT launch arguments: a captured graph of (policy -> env step -> reward bookkeeping) can be replayed ------
+ * (rl/pz_pednet_env.py:195-254 is called once per policy step, rl/train_ppo_sb3.py:246 wraps one env; here the step index lives in
+ * device memory, so the launches of a step do not change from step to step.)
+ *   pedn_rl_clock_begin(t)    everything pending is settled on pedn_stream(), the device clock is set to step t.  The turning fractions
+ *                             of step t must be in place already (they are after pedn_rl_step(t - 1)): the first step of an episode
+ *                             runs through pedn_rl_step, whose stand-alone fractions read the gate widths behind that step's actions.
+ *   pedn_rl_step_clocked      ONE env step (apply -> action_gap x (network_loading, observe)) enqueued on `stream` (a hipStream_t; NULL =
+ *                             pedn_stream()) without touching the host's bookkeeping: no allocation, no synchronisation, no event query --
+ *                             safe under stream capture.  `actions` is a device pointer [n_replicas][n_actions] (or NULL) read when
+ *                             the launch RUNS: a replayed graph reads whatever the buffer holds then.  The step's last launch advances
+ *                             the clock; a step enqueued beyond the horizon T does nothing.  Observations / rewards: pedn_rl_device_ptr.
+ *                             The caller orders `stream` behind pedn_stream() once after pedn_rl_clock_begin.
+ *   pedn_rl_clock_end(&t)     synchronises the DEVICE, reads the clock back (t = the next step to run) and restores the host's
+ *                             bookkeeping; every other entry point that steps, reads or changes the state does this implicitly first. */
+int pedn_rl_clock_begin(pedn_sim* sim, int32_t t);
+int pedn_rl_step_clocked(pedn_sim* sim, const double* actions, int32_t action_gap, void* stream);
+int pedn_rl_clock_end(pedn_sim* sim, int32_t* t);
+/* 1 while a clocked section is open (pedn_rl_clock_begin .. the next call that ends it), else 0: a caller that replays a captured
+ * graph checks this before every replay -- another entry point may have ended the section -- and begins it again if need be */
+int pedn_rl_clocked(pedn_sim* sim);
 /* device buffers for zero-copy consumers: 0 actions (f64 [R][n_actions]), 1 observations (f32 [R][n_obs]), 2 rewards (f32 [R][n_agents]) */
 void* pedn_rl_device_ptr(pedn_sim* sim, int32_t which);
 

@@ -30,10 +30,7 @@ struct pedn_sim {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int device = 0;
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
-  int node_waves = 8, node_waves_pr = 6;  // register budget of node_kernel (waves per SIMD) with shared / per-replica link parameters, see pedn_create
-  int lu_waves = 8, lu_waves_pr = 6;      // the same for the instantiation that performs the link update (node_kernel<LU>)
   int link_owner = 0;  // pedn_run: node_kernel(t + 1)'s slot waves perform the link update of t (one launch per step), PEDN_LINK_OWNER
-  int rl_owner = 0;    // pedn_rl_step under the owner-wave plan (PEDN_RL_OWNER)
   // Single-launch plan of small batches with dynamic turning fractions (inline_tf): every device-computed row is short enough for ONE
   // wave and its probabilities fit PEDN_TF_INL_ROWS LDS rows (inline_tf_ok), and the whole node_kernel grid is one generation at 4 waves
   // per SIMD: the slot waves of node_kernel<LU, TF> compute their own rows, a step is one launch.
@@ -49,27 +46,24 @@ struct pedn_sim {
   std::vector<int32_t> h_slot_trow;
   int rl_chains = 0;   // pedn_rl_step steps the two halves of the envs as two chains that stay forked ACROSS calls (PEDN_RL_CHAINS)
   int forked = 0;      // stream2 holds work of such a chain that the engine's stream does not order yet (join_forked)
-  // Persistent plan (node_persist_kernel): pedn_run's ranges of small networks in ONE launch -- the workgroups of a replica group meet
-  // between steps at a counter inside one XCD.  Eligible: the owner-wave / single-launch plan, full-record mode, the whole padded grid
-  // resident at once (<= 256 workgroups).  PEDN_PERSIST=1 (off by default: no faster than a launch per step, see the kernel).
-  int persist = 0;
-  unsigned* d_persist_bar = nullptr;   // [groups][32]: arrivals, XCC id
-  unsigned persist_base = 0;           // value of every group's arrival counter before the next launch
+  // Device-resident step clock (DevView.clock; pedn_rl_clock_begin .. pedn_rl_clock_end): while `clocked`, env steps are enqueued with
+  // constant arguments (pedn_rl_step_clocked) and the host does not know the step the device is at -- every other entry point that
+  // steps, reads or changes state first ends the clocked section (clock_end: synchronises and takes the bookkeeping back).
+  int32_t* d_clock = nullptr;
+  bool clocked = false;
+  int clock_t0 = 0;   // step the clock was set to by pedn_rl_clock_begin
   int valid_hi = 0x7fffffff;   // lazy reset: history rows above this index are neither written nor cleared (DevView.valid_hi)
   int link_pending = -1;  // owner-wave plan: step whose link update has not been performed yet, -1 none
   int fuse_obs = 1;    // pedn_rl_step: observations / rewards ride in the link update's launch (PEDN_FUSE_OBS=0: own launch)
-  // The link update as a launch of its own runs one replica per lane (link_kernel_1r: 42-47 VGPRs, 8 waves per SIMD; melbourne x 1024
-  // 12.3-12.6 against 12.7-13.1 us with two replicas per lane, profiles/r03_link_kernel_variants.txt); inside link_turn_kernel, whose
-  // budget is set by the turning fractions, it keeps two replicas per lane (half the workgroups).  PEDN_LINK_NS=1|2 forces two replicas
-  // per lane in 1 | 2 segments of 128 replicas everywhere.
-  int link_ns = 0;
+  // (The link update as a launch of its own runs one replica per lane -- link_kernel_1r: 42-47 VGPRs, 8 waves per SIMD; melbourne x 1024
+  // 12.3-12.6 against 12.7-13.1 us with two replicas per lane, profiles/r03_link_kernel_variants.txt; inside link_turn_kernel, whose
+  // budget is set by the turning fractions, it keeps two replicas per lane: half the workgroups.)
   int max_degree = 0;     // largest number of incident corridors of a node
   size_t node_lds = 0;    // dynamic LDS bytes of node_kernel
   hipStream_t stream2 = nullptr;   // second half of the replicas in pedn_run (two_streams)
-  hipStream_t stream34[2] = {nullptr, nullptr};   // chains 2 and 3 of the four-chain plan (created when it is chosen)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join34[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int warmed_chains = 1;  // chains whose streams exist and were probed to overlap
-  int chains = 1;         // plan of pedn_run for long ranges: 1, 2 or 4 chains of launches (two_streams = chains > 1)
+  int chains = 1;         // plan of pedn_run for long ranges: 1 or 2 chains of launches (two_streams = chains > 1)
   int run_chains = 1;     // chains of the range being launched (launch_step / flush_links: the last chain does the bookkeeping)
   int stream_probe_attempts = 0;   // warm_chain_streams: probes run until the chains' streams were seen to overlap
   float stream_probe_ms = 0.0f;
@@ -195,58 +189,45 @@ static int stage_commit(pedn_sim* s, pedn_sim::Stage* st) {
 // step, delft 42.8 -> 64.8, profiles/r04_stream_queues.txt).  So the pairing is probed, not assumed: a 300 us spin on each stream,
 // timed together; while they do not overlap another candidate for stream2 is created (the rejected ones stay alive until the
 // search ends, so that the runtime moves on to its other queues).
-static hipStream_t chain_stream(const pedn_sim* s, int c) { return c <= 0 ? s->stream : c == 1 ? s->stream2 : s->stream34[c - 2]; }
+static hipStream_t chain_stream(const pedn_sim* s, int c) { return c <= 0 ? s->stream : s->stream2; }
 
-// a 300 us spin on the engine's stream and on chains 1..n-1 at once; *ms = how long all of them took together
-static int probe_overlap(pedn_sim* s, int n, float* ms) {
+// a 300 us spin on the engine's stream and on stream2 at once; *ms = how long both took together
+static int probe_overlap(pedn_sim* s, float* ms) {
   HIP_TRY(s, hipEventRecord(s->ev_fork, s->stream));
-  for (int c = 1; c < n; ++c) HIP_TRY(s, hipStreamWaitEvent(chain_stream(s, c), s->ev_fork, 0));
+  HIP_TRY(s, hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
   HIP_TRY(s, hipEventRecord(s->ev0, s->stream));
-  for (int c = 0; c < n; ++c) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, chain_stream(s, c), 30000ull);   // ticks of the constant 100 MHz clock
-  for (int c = 1; c < n; ++c) {
-    hipEvent_t ev = c == 1 ? s->ev_join : s->ev_join34[c - 2];
-    HIP_TRY(s, hipEventRecord(ev, chain_stream(s, c)));
-    HIP_TRY(s, hipStreamWaitEvent(s->stream, ev, 0));
-  }
+  for (int c = 0; c < 2; ++c) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, chain_stream(s, c), 30000ull);   // ticks of the constant 100 MHz clock
+  HIP_TRY(s, hipEventRecord(s->ev_join, s->stream2));
+  HIP_TRY(s, hipStreamWaitEvent(s->stream, s->ev_join, 0));
   HIP_TRY(s, hipEventRecord(s->ev1, s->stream));
   HIP_TRY(s, hipEventSynchronize(s->ev1));
   HIP_TRY(s, hipEventElapsedTime(ms, s->ev0, s->ev1));
   return PEDN_OK;
 }
-// Streams for `want` chains (2 or 4), each probed to overlap with the ones before it; returns through *got how many chains have
-// streams that really run side by side (the plan falls back to that many).
-static int warm_chain_streams(pedn_sim* s, int want, int* got) {
+// The second chain's stream, probed to overlap with the engine's; *got = 2 when the two really run side by side, else 1 (the plan
+// falls back to one chain).  (Four chains were built and measured no faster: profiles/r04_four_chains.txt.)
+static int warm_chain_streams(pedn_sim* s, int* got) {
   *got = 1;
-  for (int c = 2; c < want; ++c) {   // chains 2, 3: created on demand
-    if (!s->stream34[c - 2]) HIP_TRY(s, hipStreamCreateWithFlags(&s->stream34[c - 2], hipStreamNonBlocking));
-    if (!s->ev_join34[c - 2]) HIP_TRY(s, hipEventCreateWithFlags(&s->ev_join34[c - 2], hipEventDisableTiming));
-  }
   bool probe = true;
   if (const char* f = getenv("PEDN_STREAM_PROBE")) probe = atoi(f) != 0;
+  if (!probe) { *got = 2; return PEDN_OK; }
   std::vector<hipStream_t> rejected;
   int rc = PEDN_OK, attempts = 0;
-  for (int n = 2; n <= want && rc == PEDN_OK; ++n) {   // chain n - 1 against chains 0 .. n - 2
-    bool ok = !probe;
-    for (int attempt = 0; attempt < 10 && !ok && rc == PEDN_OK; ++attempt) {
-      float ms = 0.0f;
-      rc = probe_overlap(s, n, &ms);   // the first pass pays for whatever the runtime sets up lazily (queue creation: ~0.2 ms)
-      if (rc == PEDN_OK) rc = probe_overlap(s, n, &ms);
-      if (rc != PEDN_OK) break;
-      ++attempts;
-      s->stream_probe_ms = ms;
-      if (ms < 0.45f) { ok = true; break; }        // overlapped: 0.3 ms + overheads; one behind another: >= 0.6 ms
-      hipStream_t next = nullptr;
-      if (hipStreamCreateWithFlags(&next, hipStreamNonBlocking) != hipSuccess) break;   // keep what we have
-      hipStream_t& slot = n == 2 ? s->stream2 : s->stream34[n - 3];
-      rejected.push_back(slot);
-      slot = next;
-    }
-    if (!ok) break;
-    *got = n;
+  for (int attempt = 0; attempt < 10 && rc == PEDN_OK; ++attempt) {
+    float ms = 0.0f;
+    rc = probe_overlap(s, &ms);   // the first pass pays for whatever the runtime sets up lazily (queue creation: ~0.2 ms)
+    if (rc == PEDN_OK) rc = probe_overlap(s, &ms);
+    if (rc != PEDN_OK) break;
+    ++attempts;
+    s->stream_probe_ms = ms;
+    if (ms < 0.45f) { *got = 2; break; }        // overlapped: 0.3 ms + overheads; one behind another: >= 0.6 ms
+    hipStream_t next = nullptr;
+    if (hipStreamCreateWithFlags(&next, hipStreamNonBlocking) != hipSuccess) break;   // keep what we have
+    rejected.push_back(s->stream2);
+    s->stream2 = next;
   }
-  if (probe) s->stream_probe_attempts = attempts;
+  s->stream_probe_attempts = attempts;
   for (hipStream_t x : rejected) hipStreamDestroy(x);
-  if (!probe) *got = want;
   return rc;
 }
 
@@ -309,6 +290,7 @@ static int catch_up(pedn_sim* s, int upto) {
       // sending / receiving flow of step t are entries t - 1: entry valid_hi belongs to the step that is being skipped
       const size_t n_1 = (size_t)v.L * v.RS;
       hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n_1 + 255) / 256)), dim3(256), 0, s->stream, view, s->valid_hi, 1, 16);
+      HIP_TRY(s, hipGetLastError());
       const size_t n_l = (size_t)(b - a) * v.L * v.RS;
       hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((n_l + 255) / 256)), dim3(256), 0, s->stream, view, a, b - a, 8);
       rc = hipGetLastError() == hipSuccess ? PEDN_OK : fail(s, PEDN_E_DEVICE, "init_state_kernel");
@@ -467,8 +449,7 @@ static inline void pending_links_first(pedn_sim* s);
 static inline void join_forked(pedn_sim* s);
 typedef void (*node_kernel_fn)(DevView, int);
 static node_kernel_fn node_kernel_for(const pedn_sim* s, bool lu, bool tf);
-typedef void (*persist_kernel_fn)(DevView, int, int, unsigned*, unsigned, int, int);
-static persist_kernel_fn persist_kernel_for(const pedn_sim* s);
+static int clock_end(pedn_sim* s);
 static void prewarm_chains(pedn_sim* s);
 
 int pedn_abi_version(void) { return PEDN_ABI_VERSION; }
@@ -540,7 +521,8 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       // randomisers: free_flow_speed x U(0.6, 0.9) stretches the shock-wave look-back by up to 1 / 0.6 (env_loader.py:410-412; the
       // k_critical / k_jam factor cancels in the shock-wave speed unless a floor binds -- then pedn_set_link_params /
       // pedn_randomize_scenarios refuse the scenario)
-      v.m64[F_CO] = ring((int)((double)max_sw / 0.6) + 3);
+      // (a look-back of x.5 before rounding divided by 0.6 can round one further up than max_sw / 0.6: sized for that)
+      v.m64[F_CO] = ring((int)ceil(((double)max_sw + 0.5) / 0.6) + 2);
       v.m64[F_OUT] = v.m64[F_S] = v.m64[F_R] = v.m64[F_GATE] = ring(4);   // [t], [t-1], [t-2] at most
       v.m32[G_TT] = ring(v.W + 2);        // travel_time[t - W] leaves the moving average (link.py:183-186)
       v.m32[G_ATT] = v.m32[G_N] = v.m32[G_K] = v.m32[G_V] = v.m32[G_LF] = ring(4);
@@ -679,8 +661,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.cost > b.cost; });
     std::vector<Row> packed;
     std::vector<int> lds_base;
-    int coop_groups = PEDN_TF_COOP_GROUPS;  // rows with more multi-entry groups get a workgroup of their own; PEDN_TF_COOP=n overrides
-    if (const char* d = getenv("PEDN_TF_COOP")) coop_groups = std::max(1, atoi(d));
+    const int coop_groups = PEDN_TF_COOP_GROUPS;  // rows with more multi-entry groups get a workgroup of their own (2..12 measured: 8 best)
     int lds_limit = PEDN_TF_LDS_ROWS;  // diagnostics: PEDN_TF_LDS_LIMIT=n gives a row at most n LDS rows (the rest goes to ent_p)
     if (const char* d = getenv("PEDN_TF_LDS_LIMIT")) lds_limit = std::max(0, std::min(atoi(d), PEDN_TF_LDS_ROWS));
     {
@@ -826,29 +807,6 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     if (by_load)
       for (int n = 0; n < N; ++n) load[n] = m->turn_pair_ptr[m->node_turn_ptr[n + 1]] - m->turn_pair_ptr[m->node_turn_ptr[n]];
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] != load[b] ? load[a] > load[b] : deg(a) > deg(b); });
-    // PEDN_PACK_ORDER=1 (a diagnostic): nodes in breadth-first order over the network instead, so that the two end nodes of a corridor
-    // sit in blocks that are dispatched close together (both read the corridor's flows of the last step under the owner-wave plan)
-    if (const char* f = getenv("PEDN_PACK_ORDER")) if (atoi(f) == 1) {
-      std::vector<int> start_of(m->n_links + m->n_vlinks, -1);
-      for (int n = 0; n < N; ++n)
-        for (int k = m->node_slot_ptr[n]; k < m->node_slot_ptr[n + 1]; ++k) start_of[m->slot_out_link[k]] = n;
-      std::vector<char> seen(N, 0);
-      std::vector<int> bfs;
-      for (int root = 0; root < N; ++root) {
-        if (seen[root]) continue;
-        seen[root] = 1;
-        bfs.push_back(root);
-        for (size_t h = bfs.size() - 1; h < bfs.size(); ++h) {
-          const int n = bfs[h];
-          for (int k = m->node_slot_ptr[n]; k < m->node_slot_ptr[n + 1]; ++k) {
-            const int lin = m->slot_in_link[k];
-            const int u = lin < L ? start_of[lin] : -1;
-            if (u >= 0 && !seen[u]) { seen[u] = 1; bfs.push_back(u); }
-          }
-        }
-      }
-      order = bfs;
-    }
     std::vector<std::vector<int>> bins;
     std::vector<int> fill;
     for (int n : order) {
@@ -892,35 +850,20 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
         tiles = std::max(tiles, t2);
       }
       s->node_lds = (size_t)((m->node_model == PEDN_NODE_OPTIMAL ? 16 : 8) + tiles) * 64 * sizeof(double);
-      if (const char* f = getenv("PEDN_NODE_LDS_FULL")) if (atoi(f)) s->node_lds = (size_t)(16 + 64) * 64 * sizeof(double);
-      // diagnostic: request at least this many bytes, i.e. hold node_kernel to fewer than 4 blocks per CU (wave places left for the
-      // other chain's launches under the two-chain plan)
-      if (const char* f = getenv("PEDN_NODE_LDS_MIN")) s->node_lds = std::max(s->node_lds, (size_t)atoi(f));
     }
-    // register budget of node_kernel: compiled for 8 waves per SIMD (64 VGPRs, a few SGPR spills) or for 6 (measured: delft 32.6
-    // against 35.0 us, melbourne 25.8 against 27.1); PEDN_NODE_WAVES=6|8 overrides
-    // with per-replica link parameters (node_kernel<PR>: 28 more live vector registers) the budget of 8 waves costs 2..8 vector
-    // spills; at 6 waves there is none and the randomised RL step is 2 % faster (profiles/r03_pr_waves.txt)
-    // a node of 7 or 8 corridors (the instantiation unrolled for 8): 4..8 vector spills at 8 waves, none at 6
-    s->node_waves = s->max_degree <= 6 ? 8 : 6;
-    s->node_waves_pr = 6;
-    // (the node LP, assign_flows_type 'optimal', is built for 6 waves only -- at 8 it spills 4..14 vector registers -- and ignores this)
-    if (const char* w = getenv("PEDN_NODE_WAVES")) s->node_waves = s->node_waves_pr = atoi(w) == 6 ? 6 : 8;
-    s->lu_waves = s->node_waves; s->lu_waves_pr = s->node_waves_pr;
-    if (const char* w = getenv("PEDN_LU_WAVES")) s->lu_waves = s->lu_waves_pr = atoi(w) == 6 ? 6 : 8;
+    // (register budget of the node kernels: node_kernel_waves() in pedn_kernels.hpp)
     // The link update of t and the turning fractions of t+1 share one launch (both only read what node_kernel(t) and earlier
     // launches wrote); PEDN_FUSE_TP=0 gives the fractions a launch of their own in front of node_kernel(t+1).
     s->fuse_tp = 1;
     if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
-    if (const char* f = getenv("PEDN_LINK_NS")) s->link_ns = atoi(f) == 2 ? 2 : (atoi(f) == 1 ? 1 : 0);
     for (SlotRec& R : rec) { R.act = -1; R.lp = -1; }
     // two chains of launches (one per half of the replicas) in pedn_run; PEDN_STREAMS=1|2, pedn_set_streams.  Default: models
     // with dynamic turning-fraction rows from 1024 replicas -- their second launch is few long waves at 4 waves per SIMD, and the
     // other half's node_kernel fills the machine meanwhile (delft x 1024: 51.7 -> 45.3 us per step).  Without such rows the gain
     // is smaller (melbourne 38.8 -> 37.3) and the plan stays one chain, whose launches are the ones the roofline figures describe.
     s->chains = v.RS >= 1024 ? 2 : 1;
-    if (const char* f = getenv("PEDN_STREAMS")) s->chains = atoi(f) == 4 ? 4 : atoi(f) == 2 ? 2 : 1;
+    if (const char* f = getenv("PEDN_STREAMS")) s->chains = atoi(f) == 2 ? 2 : 1;
     s->two_streams = s->chains > 1;
     // Owner-wave plan of pedn_run (launch_step: lazy): node_kernel<LU>(t + 1) performs the link update of t, one launch per step.  The
     // default for models whose second launch is the link update alone (no turning fractions computed on the device): melbourne x 1024
@@ -967,7 +910,6 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
       (void)hipGetLastError();
     }
     if (s->inline_tf) s->link_owner = 1;
-    if (const char* f = getenv("PEDN_RL_OWNER")) s->rl_owner = atoi(f) != 0;
     // 0 = by batch: two chains where the step is not a pure chain of latencies any more -- from 4096 envs, and from 1024 with per-env
     // scenarios (45_intersections: 2048 envs plain 24.8-25.2 -> 24.7-25.7 us per env step, randomised 27.5-27.9 -> 25.6-26.0;
     // 4096 envs 40.6 -> 35.9; profiles/r04_rl_chains.txt); PEDN_RL_CHAINS=1|2 forces
@@ -1010,6 +952,9 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     v.turn_tab = s->d_turn_tab;
     HIP_TRY(s, hipMemset(s->d_turn_tab, 0, (size_t)std::max(m->n_turns, 1) * T1 * sizeof(double)));
     TRY(dalloc(s, RS, &v.flags));
+    TRY(dalloc(s, 4, &s->d_clock));
+    HIP_TRY(s, hipMemset(s->d_clock, 0, 4 * sizeof(int32_t)));
+    v.clock = s->d_clock;
   }
   // initial widths, turning fractions, demand (broadcast to every replica)
   {
@@ -1040,33 +985,13 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     int rc = reset_state(s);
     if (rc != PEDN_OK) { std::string keep = g_last_error; pedn_destroy(s); g_last_error = keep; return rc; }
   }
-  {  // persistent plan: see node_persist_kernel
-    const size_t groups = (size_t)v.RS / 64, padded = (groups + 7) / 8 * 8 * (size_t)s->n_blocks;
-    bool ok = s->link_owner && !s->node_lp && v.n_pairs_corr > 0 && !v.hist && padded <= 256 && (v.n_trow == 0 || s->inline_tf);
-    if (ok && (v.n_trow > 0 ? s->node_lds_tf : s->node_lds) > 64 * 1024)
-      for (int pr = 0; pr < 2 && ok; ++pr) {
-        const int keep = v.pr;
-        v.pr = pr;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(persist_kernel_for(s)), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(v.n_trow > 0 ? s->node_lds_tf : s->node_lds)) != hipSuccess) ok = false;
-        v.pr = keep;
-        (void)hipGetLastError();
-      }
-    s->persist = 0;   // opt-in: a measured negative (see node_persist_kernel)
-    if (const char* f = getenv("PEDN_PERSIST")) s->persist = atoi(f) != 0 && ok;
-    if (s->persist) {
-      std::vector<unsigned> h(groups * 32, 0u);
-      for (size_t g = 0; g < groups; ++g) h[g * 32 + 1] = 0xffffffffu;
-      TRY(upload(s, h.data(), h.size(), (const unsigned**)&s->d_persist_bar));
-    }
-  }
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   if (s->chains > 1) {
     int got = 1;
-    TRY(warm_chain_streams(s, s->chains, &got));
-    s->chains = s->warmed_chains = got == 3 ? 2 : got;
+    TRY(warm_chain_streams(s, &got));
+    s->chains = s->warmed_chains = got;
     s->two_streams = s->chains > 1;
-    if (!getenv("PEDN_NO_PREWARM")) prewarm_chains(s);
+    prewarm_chains(s);
   }
 #undef TRY
   *out = s;
@@ -1087,10 +1012,6 @@ int pedn_destroy(pedn_sim* s) {
   if (s->ev0) hipEventDestroy(s->ev0);
   if (s->ev1) hipEventDestroy(s->ev1);
   if (s->stream2) hipStreamDestroy(s->stream2);
-  for (int k = 0; k < 2; ++k) {
-    if (s->stream34[k]) hipStreamDestroy(s->stream34[k]);
-    if (s->ev_join34[k]) hipEventDestroy(s->ev_join34[k]);
-  }
   if (s->ev_fork) hipEventDestroy(s->ev_fork);
   if (s->ev_join) hipEventDestroy(s->ev_join);
   if (s->stream) hipStreamDestroy(s->stream);
@@ -1305,10 +1226,11 @@ int pedn_get_turning_fractions(pedn_sim* s, int32_t node, int32_t replica, doubl
 int pedn_set_width(pedn_sim* s, int32_t which, int32_t link, int32_t replica, double value) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (link < 0 || link >= s->v.L || which < 0 || which > 3) return fail(s, PEDN_E_ARG, "link or selector out of range");
+  if (replica != PEDN_ALL && (replica < 0 || replica >= s->v.R)) return fail(s, PEDN_E_ARG, "replica out of range");
   double* dst = which == PEDN_W_FRONT ? s->v.front : which == PEDN_W_BACK ? s->v.back : which == PEDN_W_SEP ? s->v.sepw : s->v.sepnp;
-  if (which == PEDN_W_BACK) s->tp_ready = -1;  // capacity fallback of the turn probabilities (path_finder.py:575-576)
-  hipSetDevice(s->device);
+  HIP_TRY(s, hipSetDevice(s->device));
   pending_links_first(s);     // the link update records the gate / reads the separator width of its own step
+  if (which == PEDN_W_BACK) s->tp_ready = -1;  // capacity fallback of the turn probabilities (path_finder.py:575-576)
   int rc = push_rows(s, dst, &value, 1, (size_t)link, 1, replica);
   if (rc != PEDN_OK || which > PEDN_W_BACK) return rc;
   (which == PEDN_W_FRONT ? s->h_front_u : s->h_back_u)[link] = replica == PEDN_ALL ? value : __builtin_nan("");
@@ -1376,61 +1298,46 @@ int pedn_get_widths(pedn_sim* s, int32_t which, double* values) {
 }
 
 // lu: the instantiation whose slot waves perform the link update of step t-1 themselves (node_kernel<..., LU = true>)
+// tf: ... and compute their own rows of turning fractions (node_kernel<.., TF> / with helper waves node_kernel_h)
 static node_kernel_fn node_kernel_for(const pedn_sim* s, bool lu, bool tf) {
   const bool h = s->v.hist != 0;  // recent-history mode: the instantiations that mask the history rows
   const bool d6 = s->max_degree <= 6;  // loops and the row of turning fractions unrolled for 6 instead of 8 corridors per node
-#define PEDN_NK(PR_, W_, LP_, LU_) (h ? (d6 ? node_kernel<PR_, W_, LP_, true, 6, LU_> : node_kernel<PR_, W_, LP_, true, 8, LU_>) \
-                                      : (d6 ? node_kernel<PR_, W_, LP_, false, 6, LU_> : node_kernel<PR_, W_, LP_, false, 8, LU_>))
-  if (s->node_lp) return s->v.pr ? PEDN_NK(true, 6, true, false) : PEDN_NK(false, 6, true, false);   // at 8 waves the LP instantiations spill 4..14 vector registers
+#define PEDN_NK(PR_, LP_, LU_, TF_) (h ? (d6 ? node_kernel<PR_, LP_, true, 6, LU_, TF_> : node_kernel<PR_, LP_, true, 8, LU_, TF_>) \
+                                       : (d6 ? node_kernel<PR_, LP_, false, 6, LU_, TF_> : node_kernel<PR_, LP_, false, 8, LU_, TF_>))
+  if (s->node_lp) return s->v.pr ? PEDN_NK(true, true, false, false) : PEDN_NK(false, true, false, false);
   if (lu && tf && s->inline_help) {   // helper waves compute the rows: sixteen waves per workgroup
     if (s->v.pr) return h ? (d6 ? node_kernel_h<true, true, 6> : node_kernel_h<true, true, 8>) : (d6 ? node_kernel_h<true, false, 6> : node_kernel_h<true, false, 8>);
     return h ? (d6 ? node_kernel_h<false, true, 6> : node_kernel_h<false, true, 8>) : (d6 ? node_kernel_h<false, false, 6> : node_kernel_h<false, false, 8>);
   }
-  if (lu && tf) {   // the slot waves compute their own rows of turning fractions: 2 waves per SIMD (at 4 -- 128 VGPRs -- 59 vector spills)
-#define PEDN_NKT(PR_) (h ? (d6 ? node_kernel<PR_, 2, false, true, 6, true, true> : node_kernel<PR_, 2, false, true, 8, true, true>) \
-                         : (d6 ? node_kernel<PR_, 2, false, false, 6, true, true> : node_kernel<PR_, 2, false, false, 8, true, true>))
-    return s->v.pr ? PEDN_NKT(true) : PEDN_NKT(false);
-#undef PEDN_NKT
-  }
-  if (lu) {
-    if (s->v.pr) return s->lu_waves_pr == 8 ? PEDN_NK(true, 8, false, true) : PEDN_NK(true, 6, false, true);
-    return s->lu_waves == 8 ? PEDN_NK(false, 8, false, true) : PEDN_NK(false, 6, false, true);
-  }
-  if (s->v.pr) return s->node_waves_pr == 8 ? PEDN_NK(true, 8, false, false) : PEDN_NK(true, 6, false, false);
-  return s->node_waves == 8 ? PEDN_NK(false, 8, false, false) : PEDN_NK(false, 6, false, false);
+  if (lu && tf) return s->v.pr ? PEDN_NK(true, false, true, true) : PEDN_NK(false, false, true, true);
+  if (lu) return s->v.pr ? PEDN_NK(true, false, true, false) : PEDN_NK(false, false, true, false);
+  return s->v.pr ? PEDN_NK(true, false, false, false) : PEDN_NK(false, false, false, false);
 #undef PEDN_NK
 }
 
-// full-record mode only; built for 2 waves per SIMD (one workgroup per CU is all the plan ever places; at 6 the loop-carried kernel
-// arguments cost 270 B of scratch per lane)
-static persist_kernel_fn persist_kernel_for(const pedn_sim* s) {
-  const bool d6 = s->max_degree <= 6;
-  if (s->v.n_trow > 0) {
-    if (s->v.pr) return d6 ? node_persist_kernel<true, 2, false, 6, true> : node_persist_kernel<true, 2, false, 8, true>;
-    return d6 ? node_persist_kernel<false, 2, false, 6, true> : node_persist_kernel<false, 2, false, 8, true>;
-  }
-  if (s->v.pr) return d6 ? node_persist_kernel<true, 2, false, 6, false> : node_persist_kernel<true, 2, false, 8, false>;
-  return d6 ? node_persist_kernel<false, 2, false, 6, false> : node_persist_kernel<false, 2, false, 8, false>;
+// the node kernel of a clocked env step (pedn_rl_step_clocked): the step index comes from DevView.clock
+static node_kernel_fn clocked_node_kernel_for(const pedn_sim* s) {
+  const bool h = s->v.hist != 0, d6 = s->max_degree <= 6;
+#define PEDN_NKC(PR_) (h ? (d6 ? node_kernel<PR_, false, true, 6, false, false, true> : node_kernel<PR_, false, true, 8, false, false, true>) \
+                         : (d6 ? node_kernel<PR_, false, false, 6, false, false, true> : node_kernel<PR_, false, false, 8, false, false, true>))
+  return s->v.pr ? PEDN_NKC(true) : PEDN_NKC(false);   // (not built for the node LP: pedn_rl_clock_begin refuses)
+#undef PEDN_NKC
 }
 
 // The link update of step t as a launch of its own (the second launch of a step of a model without dynamic turning fractions, and
-// the flush of a pending update under the owner-wave plan).  e >= 0: start / stop events ev[e], ev[e + 1].
-static unsigned link_blocks(const pedn_sim* s, const DevView& v, bool one_r, int ns) {
-  return v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (one_r ? v.subRS : v.subRS / (2 * ns)) + 255) / 256) : 0u;
+// the flush of a pending update under the owner-wave plan): one replica per lane.  e >= 0: start / stop events ev[e], ev[e + 1].
+static unsigned link_blocks(const DevView& v, bool one_r) {
+  return v.n_pairs_corr > 0 ? (unsigned)(((size_t)v.n_pairs_corr * (one_r ? v.subRS : v.subRS / 2) + 255) / 256) : 0u;
 }
 static void launch_link_update(pedn_sim* s, const DevView& v, hipStream_t stream, int t, hipEvent_t* ev, int e) {
   auto launch = [&](auto kernel, dim3 grid, dim3 block, auto... args) {
     if (ev) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev[e], ev[e + 1], 0, args...);
     else hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
   };
-  const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0) ? 2 : 1;
-  const bool one_r = v.pr || s->link_ns == 0;   // one replica per lane (link_kernel_1r)
-  const unsigned nlb = link_blocks(s, v, one_r, ns);
+  const unsigned nlb = link_blocks(v, true);
   if (nlb == 0) return;
   if (v.pr) { if (v.hist) launch(link_kernel_1r<true, true>, dim3(nlb), dim3(256), v, t); else launch(link_kernel_1r<true, false>, dim3(nlb), dim3(256), v, t); }
-  else if (one_r) { if (v.hist) launch(link_kernel_1r<false, true>, dim3(nlb), dim3(256), v, t); else launch(link_kernel_1r<false, false>, dim3(nlb), dim3(256), v, t); }
-  else if (ns == 2) { if (v.hist) launch(link_kernel<2, true>, dim3(nlb), dim3(256), v, t); else launch(link_kernel<2, false>, dim3(nlb), dim3(256), v, t); }
-  else { if (v.hist) launch(link_kernel<1, true>, dim3(nlb), dim3(256), v, t); else launch(link_kernel<1, false>, dim3(nlb), dim3(256), v, t); }
+  else { if (v.hist) launch(link_kernel_1r<false, true>, dim3(nlb), dim3(256), v, t); else launch(link_kernel_1r<false, false>, dim3(nlb), dim3(256), v, t); }
 }
 
 // this launch's share of the batch: the whole of it on the engine's stream (half = -1) or one half of the replicas per stream
@@ -1467,6 +1374,7 @@ static int join_chains(pedn_sim* s, int n);
 // that the engine's stream does not order stream2's work yet: joined first.  Anything that enqueues on the engine's stream or reads
 // device memory calls this, i.e. every entry point but the stepping calls themselves and the pure host getters.)
 static inline void join_forked(pedn_sim* s) {
+  if (s->clocked) clock_end(s);   // whoever needs the host's view of the state ends a clocked section first (synchronises)
   if (s->forked) {
     s->forked = 0;
     join_chains(s, 2);
@@ -1494,9 +1402,9 @@ static void prewarm_chains(pedn_sim* s) {
     hipStream_t st = chain_stream(s, c);
     for (int lu = 0; lu < 2; ++lu) hipLaunchKernelGGL(node_kernel_for(s, lu != 0, false), dim3(1, 1), dim3(512), s->node_lds, st, v, 2);
     if (s->inline_tf) hipLaunchKernelGGL(node_kernel_for(s, true, true), dim3(1, 1), dim3(s->inline_help ? 1024 : 512), s->node_lds_tf, st, v, 2);
-    if (vl.hist) { hipLaunchKernelGGL((link_turn_kernel<false, false, 1, true>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
+    if (vl.hist) { hipLaunchKernelGGL((link_turn_kernel<false, false, true>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
                    hipLaunchKernelGGL((link_kernel_1r<false, true>), dim3(1), dim3(256), 0, st, vl, 1); }
-    else { hipLaunchKernelGGL((link_turn_kernel<false, false, 1, false>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
+    else { hipLaunchKernelGGL((link_turn_kernel<false, false, false>), dim3(1), dim3(256), 0, st, vl, 1, 0u, 0u, 0u, q, 0);
            hipLaunchKernelGGL((link_kernel_1r<false, false>), dim3(1), dim3(256), 0, st, vl, 1); }
   }
   for (int c = s->chains - 1; c >= 0; --c) hipStreamSynchronize(chain_stream(s, c));
@@ -1508,7 +1416,10 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
                        const double* fold_actions = nullptr, int half = -1, bool lazy = false) {
   // half = -1: the whole batch on the engine's stream; 0 / 1: the first / second half of the replicas on stream / stream2 (the
   // caller, pedn_run, launches both halves of a step and does the per-step bookkeeping once, after the second one)
-  if (half < 0 && t - 1 > s->valid_hi) catch_up(s, t - 1);   // a step that skips ahead after a lazy reset (chains: their callers do this before the fork)
+  if (half < 0 && t - 1 > s->valid_hi) {   // a step that skips ahead after a lazy reset (chains: their callers do this before the fork)
+    const int rc = catch_up(s, t - 1);
+    if (rc != PEDN_OK) return rc;
+  }
   hipStream_t stream;
   DevView v = view_of(s, half, &stream);
   lazy = lazy && !s->node_lp && v.n_pairs_corr > 0;
@@ -1545,10 +1456,9 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
   if (ev) hipExtLaunchKernelGGL(node_kernel_for(s, lu, inl), dim3(rgroups, (unsigned)s->n_blocks), nblock, nlds, stream, ev[2], ev[3], 0, vn, t);
   else hipLaunchKernelGGL(node_kernel_for(s, lu, inl), dim3(rgroups, (unsigned)s->n_blocks), nblock, nlds, stream, vn, t);
   if (inl && last_chain(s, half)) s->tp_ready = t;   // the fractions of t are in tfd[t & 1] (a following step that cannot inline computes its own)
-  // link update: two replicas per lane in NS segments of 128 replicas (link_body); NS = 2 needs RS to be a multiple of 256
-  const int ns = (!v.pr && s->link_ns == 2 && v.subRS % 256 == 0 && !obs_fused) ? 2 : 1;   // (the diagnostic NS = 2 has no OBS instantiation)
-  const bool one_r = v.pr || (s->link_ns == 0 && !fused && !obs_fused);   // one replica per lane (link_kernel_1r)
-  const unsigned nlb = lazy ? 0u : link_blocks(s, v, one_r, ns);   // lazy: no link-update workgroups in this step's second launch
+  // link update: one replica per lane as a launch of its own and with per-replica parameters, two inside link_turn_kernel (link_body)
+  const bool one_r = v.pr || (!fused && !obs_fused);
+  const unsigned nlb = lazy ? 0u : link_blocks(v, one_r);   // lazy: no link-update workgroups in this step's second launch
   if (last_chain(s, half)) s->link_pending = lazy ? t : -1;
   s->second_launch = 1;
   if (fused || obs_fused) {
@@ -1559,16 +1469,15 @@ static int launch_step(pedn_sim* s, int t, hipEvent_t* ev = nullptr, int observe
     if (!obs_fused) q.n_agents = 0;
     const int acc = observe > 0 ? 1 : 0;
     const dim3 grid(nlb + ntb + nob), block(256);
-    // instantiation by (per-replica parameters, observations in the launch, segments per lane, recent-history mode)
-#define PEDN_LT(PR_, OBS_, NS_) do { if (v.hist) launch(link_turn_kernel<PR_, OBS_, NS_, true>, grid, block, 4, v, t, nlb, ntb, nth, q, acc); \
-                                     else launch(link_turn_kernel<PR_, OBS_, NS_, false>, grid, block, 4, v, t, nlb, ntb, nth, q, acc); } while (0)
+    // instantiation by (per-replica parameters, observations in the launch, recent-history mode)
+#define PEDN_LT(PR_, OBS_) do { if (v.hist) launch(link_turn_kernel<PR_, OBS_, true>, grid, block, 4, v, t, nlb, ntb, nth, q, acc); \
+                                else launch(link_turn_kernel<PR_, OBS_, false>, grid, block, 4, v, t, nlb, ntb, nth, q, acc); } while (0)
     if (obs_fused) {
-      if (v.pr) PEDN_LT(true, true, 1);
-      else PEDN_LT(false, true, 1);
+      if (v.pr) PEDN_LT(true, true);
+      else PEDN_LT(false, true);
     } else {
-      if (v.pr) PEDN_LT(true, false, 1);
-      else if (ns == 2) PEDN_LT(false, false, 2);
-      else PEDN_LT(false, false, 1);
+      if (v.pr) PEDN_LT(true, false);
+      else PEDN_LT(false, false);
     }
 #undef PEDN_LT
     if (fused && last_chain(s, half)) s->tp_ready = t + 1;   // the other chains of this step still have to see the old value
@@ -1589,6 +1498,8 @@ int pedn_step(pedn_sim* s, int32_t t) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
   HIP_TRY(s, hipSetDevice(s->device));
+  int rc = clock_end(s);
+  if (rc != PEDN_OK) return rc;
   join_forked(s);
   // owner-wave plan: this step's link update stays pending -- the next step's node kernel performs it, or whatever call looks at
   // or changes the state first (pending_links_first)
@@ -1598,7 +1509,7 @@ int pedn_step(pedn_sim* s, int32_t t) {
     if (s->touch_streak >= 2) lazy = false;
   }
   s->touched = 0;
-  launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, lazy);
+  if ((rc = launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, lazy)) != PEDN_OK) return rc;
   HIP_TRY(s, hipGetLastError());
   return PEDN_OK;
 }
@@ -1627,7 +1538,6 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
 // pedn_run's plan for the range [t0, t1): how many chains of launches (each a share of the replicas on its own stream)?
 static int chains_for(const pedn_sim* s, int t0, int t1) {
   if (s->chains < 2 || t1 - t0 < 8) return 1;
-  if (s->chains == 4 && s->v.RS % 512 == 0) return 4;
   return s->v.RS % 256 == 0 ? 2 : 1;
 }
 
@@ -1642,9 +1552,8 @@ static int fork_chains(pedn_sim* s, int n) {
 static int join_chains(pedn_sim* s, int n) {
   hipError_t e = hipSuccess;
   for (int c = 1; c < n && e == hipSuccess; ++c) {
-    hipEvent_t ev = c == 1 ? s->ev_join : s->ev_join34[c - 2];
-    e = hipEventRecord(ev, chain_stream(s, c));
-    if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, ev, 0);
+    e = hipEventRecord(s->ev_join, chain_stream(s, c));
+    if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->ev_join, 0);
   }
   if (e != hipSuccess) {
     for (int c = n - 1; c >= 0; --c) hipStreamSynchronize(chain_stream(s, c));
@@ -1664,42 +1573,23 @@ int pedn_run(pedn_sim* s, int32_t t0, int32_t t1) {
   // Owner-wave plan (link_owner): one launch per step for models without dynamic turning fractions -- node_kernel<LU>(t) performs the
   // link update of t - 1 -- plus one link_kernel for the last step of the range.
   const bool lazy = s->link_owner != 0;
+  int rc = clock_end(s);
+  if (rc != PEDN_OK) return rc;
   join_forked(s);
-  const bool persist = s->persist && lazy && t1 - t0 >= 3;
-  const int nch = persist ? 1 : chains_for(s, t0, t1);
+  const int nch = chains_for(s, t0, t1);
   if (nch > 1) {
     if (s->link_pending >= 0 && s->link_pending != t0 - 1) pending_links_first(s);   // a stale pending update: on the whole batch, before the fork
-    if (t0 - 1 > s->valid_hi) catch_up(s, t0 - 1);
-    int rc = fork_chains(s, nch);
-    if (rc != PEDN_OK) return rc;
+    if (t0 - 1 > s->valid_hi && (rc = catch_up(s, t0 - 1)) != PEDN_OK) return rc;
+    if ((rc = fork_chains(s, nch)) != PEDN_OK) return rc;
     s->run_chains = nch;
     for (int t = t0; t < t1; ++t)
       for (int c = 0; c < nch; ++c) launch_step(s, t, nullptr, -1, nullptr, nullptr, c, lazy);
     s->run_chains = 1;
     rc = join_chains(s, nch);    // the last step's link update stays pending on the joined stream (pending_links_first)
     if (rc != PEDN_OK) return rc;
-  } else if (persist) {
-    // persistent plan: the first step as a launch of its own unless it is the step the pending link update waits for, the rest of
-    // the range in ONE launch (every step of it is node_kernel<LU[, TF]>'s), the last step's link update stays pending as always
-    int t = t0;
-    if (!(s->link_pending == t - 1 && t >= 2)) launch_step(s, t++, nullptr, -1, nullptr, nullptr, -1, lazy);
-    DevView& v = s->v;
-    if (s->valid_hi != 0x7fffffff) {   // after a lazy reset: the rows of the range are cleared now (the kernel's view cannot move with t)
-      const int rc = catch_up(s, t1 - 1);
-      if (rc != PEDN_OK) return rc;
-    }
-    const int groups = v.RS / 64, nb = s->n_blocks;
-    const unsigned grid = (unsigned)((groups + 7) / 8 * 8 * nb);
-    const size_t nlds = v.n_trow > 0 ? s->node_lds_tf : s->node_lds;
-    hipLaunchKernelGGL(persist_kernel_for(s), dim3(grid), dim3(512), nlds, s->stream, v, t, t1, s->d_persist_bar, s->persist_base, nb, groups);
-    s->persist_base += (unsigned)nb * (unsigned)(t1 - t - 1);
-    if (v.n_trow > 0) s->tp_ready = t1 - 1;
-    s->link_pending = t1 - 1;
-    if (s->valid_hi != 0x7fffffff && t1 - 1 > s->valid_hi) s->valid_hi = v.valid_hi = t1 - 1;
-    s->last_t = t1 - 1;
-    s->step_epoch += t1 - t;
   } else {
-    for (int t = t0; t < t1; ++t) launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, lazy);
+    for (int t = t0; t < t1; ++t)
+      if ((rc = launch_step(s, t, nullptr, -1, nullptr, nullptr, -1, lazy)) != PEDN_OK) return rc;
   }
   HIP_TRY(s, hipGetLastError());
   return PEDN_OK;
@@ -1711,25 +1601,26 @@ int pedn_plan_info(pedn_sim* s, int32_t* info, int32_t n) {
   info[1] = s->link_owner && !s->node_lp && s->v.n_pairs_corr > 0;   // (with device-computed rows: the single-launch plan, inline_tf)
   info[2] = s->stream_probe_attempts;
   info[3] = (int32_t)(s->stream_probe_ms * 1000.0f + 0.5f);
-  if (n >= 5) info[4] = s->persist;   // ranges of pedn_run as one persistent launch
+  if (n >= 5) info[4] = 0;   // (reserved: the persistent plan of round 4 was removed)
   return PEDN_OK;
 }
 
 int pedn_set_streams(pedn_sim* s, int32_t n) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
-  if (n != 1 && n != 2 && n != 4) return fail(s, PEDN_E_ARG, "1, 2 or 4 chains of launches");
-  if (n > 1 && n > s->warmed_chains) {
-    HIP_TRY(s, hipSetDevice(s->device));
-  pending_links_first(s);
+  if (n != 1 && n != 2) return fail(s, PEDN_E_ARG, "1 or 2 chains of launches");
+  HIP_TRY(s, hipSetDevice(s->device));
+  int rc = clock_end(s);
+  if (rc != PEDN_OK) return rc;
+  if (n > s->warmed_chains) {
+    pending_links_first(s);
     int got = 1;
-    int rc = warm_chain_streams(s, n, &got);
-    if (rc != PEDN_OK) return rc;
-    s->warmed_chains = got == 3 ? 2 : got;
+    if ((rc = warm_chain_streams(s, &got)) != PEDN_OK) return rc;
+    s->warmed_chains = got;
   }
   const int before = s->chains;
   s->chains = n > 1 ? std::min<int>(n, std::max(s->warmed_chains, 1)) : 1;
   s->two_streams = s->chains > 1;
-  if (s->chains > before && !getenv("PEDN_NO_PREWARM")) prewarm_chains(s);
+  if (s->chains > before) prewarm_chains(s);   // (every chain's stream: hipSetDevice above)
   return PEDN_OK;
 }
 
@@ -1751,9 +1642,9 @@ static int profile_range(pedn_sim* s, int t0, int t1, std::vector<ProfRow>& rows
   std::vector<int> tp_ran((size_t)n, 0), second((size_t)n, 0);
   if (two) {
     if (s->link_pending >= 0 && s->link_pending != t0 - 1) pending_links_first(s);
-    if (t0 - 1 > s->valid_hi) catch_up(s, t0 - 1);
-    const int rc = fork_chains(s, halves);
-    if (rc != PEDN_OK) return rc;
+    int rc = PEDN_OK;
+    if (t0 - 1 > s->valid_hi && (rc = catch_up(s, t0 - 1)) != PEDN_OK) return rc;
+    if ((rc = fork_chains(s, halves)) != PEDN_OK) return rc;
     s->run_chains = halves;
   }
   for (int t = t0, k = 0; t < t1; ++t)
@@ -1900,15 +1791,21 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
   return stage_commit(s, st);
 }
 
+int pedn_flush(pedn_sim* s) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);   // joins forked chains, ends a clocked section, performs a pending link update -- all on pedn_stream()
+  if (s->valid_hi != 0x7fffffff) {   // a zero-copy consumer may look at any row: finish what a lazy reset left out
+    const int rc = catch_up(s, s->v.T1 - 1);
+    if (rc != PEDN_OK) return rc;
+    s->valid_hi = s->v.valid_hi = 0x7fffffff;
+  }
+  return PEDN_OK;
+}
+
 void* pedn_device_ptr(pedn_sim* s, int32_t field, int64_t* columns, int64_t* replica_stride) {
   if (!s || field < 0 || field >= PEDN_N_FIELDS) return nullptr;
-  if ((s->link_pending >= 0 || s->forked || s->valid_hi != 0x7fffffff) && hipSetDevice(s->device) == hipSuccess) {
-    pending_links_first(s);   // the consumer orders itself behind pedn_stream()
-    if (s->valid_hi != 0x7fffffff) {   // a zero-copy consumer may look at any row: finish what the lazy reset left out
-      catch_up(s, s->v.T1 - 1);
-      s->valid_hi = s->v.valid_hi = 0x7fffffff;
-    }
-  }
+  if ((s->link_pending >= 0 || s->forked || s->clocked || s->valid_hi != 0x7fffffff) && pedn_flush(s) != PEDN_OK) return nullptr;
   if (columns) *columns = field < 4 ? s->v.Lall : s->v.L;
   if (replica_stride) *replica_stride = s->v.RS;
   return field < 7 ? (void*)s->v.f64[field] : (void*)s->v.f32[field - 7];
@@ -2223,6 +2120,10 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
   if (action_gap < 1 || t < 1 || t + action_gap - 1 > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "step range outside 1..T");
   int rc = PEDN_OK;
   if (!s->rl_ready) return fail(s, PEDN_E_ARG, "pedn_rl_configure has not been called");
+  if (s->clocked) {   // back to host-side step indices (the fold decision below reads tp_ready)
+    HIP_TRY(s, hipSetDevice(s->device));
+    if ((rc = clock_end(s)) != PEDN_OK) return rc;
+  }
   RlView& q = s->rl;
   // gater-only agent sets: node_kernel of the first sub-step applies the actions (one launch less).  Not when the turning
   // fractions of step t still have to be computed by their own launch in front of node_kernel: their capacity fallback reads
@@ -2248,7 +2149,7 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
   // (actions from the host go through the engine's own action buffer, which the other chain's previous step may still be reading)
   if (t - 1 > s->valid_hi) {   // skipping ahead after a lazy reset
     join_forked(s);
-    catch_up(s, t - 1);
+    if ((rc = catch_up(s, t - 1)) != PEDN_OK) return rc;
   }
   const bool by_batch = s->v.RS >= 4096 || (s->v.pr && s->v.RS >= 1024);
   // on_device == 2: the caller chains this call between its own streams and pedn_stream() with events (no host synchronisation):
@@ -2263,18 +2164,15 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
   for (int k = 0; k < action_gap; ++k) {
     const bool last = k == action_gap - 1;
     bool observed = false;
-    // owner-wave plan of the RL step (rl_owner): only with the actions folded into node_kernel and the observations in the second launch
-    // (NOT with the single-launch plan of small batches: the observations are a second launch either way, and with the rows of t + 1 riding
-    // in it the two launches are shorter -- 45_intersections x 256 envs 17.5 us per env step against 24.8, where every other step also
-    // fell back to stand-alone fractions because the actions could not be folded; profiles/r04_rl_small_batches.txt)
-    const bool lazy = !two && s->rl_owner && s->rl_fold && s->fuse_obs && (!actions || fold != nullptr);
+    // (always two launches per env step: the observations are a second launch either way, and with the rows of t + 1 riding in it the
+    // two launches are shorter than the single-launch / owner-wave plans -- profiles/r04_rl_small_batches.txt, r04_rl_owner.txt)
     if (two) {
       s->run_chains = 2;
       for (int c = 0; c < 2; ++c) launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, c, false);
       s->run_chains = 1;
       if ((last && (obs || rewards)) || !observed) join_forked(s);
     } else
-      launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, -1, lazy);
+      if ((rc = launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, -1, false)) != PEDN_OK) return rc;
     HIP_TRY(s, hipGetLastError());
     if (!observed) {
       if ((rc = pedn_rl_observe(s, t + k, k > 0, last ? obs : nullptr, last ? rewards : nullptr)) != PEDN_OK) return rc;
@@ -2284,6 +2182,96 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
       HIP_TRY(s, hipStreamSynchronize(s->stream));
     }
   }
+  return PEDN_OK;
+}
+
+// ---- device-resident step clock: env steps whose launches have constant arguments (a captured graph of them can be replayed)
+static int clock_end(pedn_sim* s) {
+  if (!s->clocked) return PEDN_OK;
+  s->clocked = false;
+  // the clocked steps may sit on a caller's stream (or in a graph replayed on one): everything on the device first
+  HIP_TRY(s, hipDeviceSynchronize());
+  int32_t h[4] = {0, 0, 0, 0};
+  HIP_TRY(s, hipMemcpy(h, s->d_clock, sizeof(h), hipMemcpyDeviceToHost));
+  const int t_now = h[0];
+  if (t_now > s->clock_t0) {   // steps clock_t0 .. t_now - 1 ran
+    s->last_t = t_now - 1;
+    s->step_epoch += t_now - s->clock_t0;
+    s->tp_ready = (s->v.n_trow > 0 && t_now <= s->v.T1 - 1) ? t_now : -1;   // link_turn_kernel(t_now - 1) left the fractions of t_now
+    s->link_pending = -1;
+  }
+  s->valid_hi = s->v.valid_hi = h[2];
+  return PEDN_OK;
+}
+
+int pedn_rl_clock_begin(pedn_sim* s, int32_t t) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (!s->rl_ready) return fail(s, PEDN_E_ARG, "pedn_rl_configure has not been called");
+  if (t < 1 || t > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "time step outside 1..T");
+  if (!s->fuse_obs || !s->fuse_tp || s->v.n_pairs_corr == 0 || s->node_lp)
+    return fail(s, PEDN_E_ARG, "the clocked step needs the fused second launch (PEDN_FUSE_OBS / PEDN_FUSE_TP), physical links and the classic node model");
+  HIP_TRY(s, hipSetDevice(s->device));
+  pending_links_first(s);   // (ends a clocked section that is still open)
+  int rc;
+  if (t - 1 > s->valid_hi && (rc = catch_up(s, t - 1)) != PEDN_OK) return rc;
+  // The fractions of step t must be in place: the stand-alone launch that would compute them reads the gate widths AFTER the actions of
+  // step t are applied (capacity fallback, path_finder.py:575-576) -- only the ordinary pedn_rl_step can order that.  True for every
+  // step but the first one after a reset or a setter.
+  if (s->v.n_trow > 0 && s->tp_ready != t)
+    return fail(s, PEDN_E_ARG, "turning fractions of step " + std::to_string(t) + " are not prepared: run this step with pedn_rl_step first");
+  hipLaunchKernelGGL(set_clock_kernel, dim3(1), dim3(64), 0, s->stream, s->d_clock, t, s->valid_hi);
+  HIP_TRY(s, hipGetLastError());
+  s->clocked = true;
+  s->clock_t0 = t;
+  return PEDN_OK;
+}
+
+int pedn_rl_step_clocked(pedn_sim* s, const double* actions, int32_t action_gap, void* stream) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (!s->clocked) return fail(s, PEDN_E_ARG, "pedn_rl_clock_begin has not been called (or the clocked section was ended by another call)");
+  if (action_gap < 1) return fail(s, PEDN_E_ARG, "action_gap < 1");
+  HIP_TRY(s, hipSetDevice(s->device));
+  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  const DevView& v = s->v;
+  RlView q = s->rl;
+  const double* fold = nullptr;
+  if (actions) {
+    if (s->rl_fold) fold = actions;   // gater-only agent set: the consuming node_kernel wave clips and applies the action
+    else {
+      RlView qq = q;
+      qq.actions = const_cast<double*>(actions);
+      const size_t n = (size_t)q.A * v.RS;
+      hipLaunchKernelGGL(rl_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, qq);
+    }
+  }
+  const unsigned rgroups = (unsigned)(v.RS / 64);
+  const bool fused = v.n_trow > 0;   // the fractions of t + 1 ride in the second launch (its workgroups idle behind the last step)
+  const unsigned nlb = link_blocks(v, v.pr != 0);
+  const unsigned ntb = fused ? (unsigned)((v.n_trow + 3) / 4) * rgroups : 0u, nth = fused ? (unsigned)s->n_tf_heavy_quads * rgroups : 0u;
+  const unsigned nob = (unsigned)q.n_agents * rgroups;
+  for (int k = 0; k < action_gap; ++k) {
+    DevView vn = v;
+    vn.rl_actions = k == 0 ? fold : nullptr;
+    hipLaunchKernelGGL(clocked_node_kernel_for(s), dim3(rgroups, (unsigned)s->n_blocks), dim3(512), s->node_lds, st, vn, -1);
+    const dim3 grid(nlb + ntb + nob), block(256);
+    const int acc = k > 0 ? 1 : 0;
+    if (v.pr) { if (v.hist) hipLaunchKernelGGL((link_turn_kernel<true, true, true, true>), grid, block, 0, st, v, -1, nlb, ntb, nth, q, acc);
+                else hipLaunchKernelGGL((link_turn_kernel<true, true, false, true>), grid, block, 0, st, v, -1, nlb, ntb, nth, q, acc); }
+    else { if (v.hist) hipLaunchKernelGGL((link_turn_kernel<false, true, true, true>), grid, block, 0, st, v, -1, nlb, ntb, nth, q, acc);
+           else hipLaunchKernelGGL((link_turn_kernel<false, true, false, true>), grid, block, 0, st, v, -1, nlb, ntb, nth, q, acc); }
+  }
+  HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
+}
+
+int pedn_rl_clocked(pedn_sim* s) { return s && s->clocked ? 1 : 0; }
+
+int pedn_rl_clock_end(pedn_sim* s, int32_t* t) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  HIP_TRY(s, hipSetDevice(s->device));
+  const int rc = clock_end(s);
+  if (rc != PEDN_OK) return rc;
+  if (t) *t = s->last_t + 1;
   return PEDN_OK;
 }
 

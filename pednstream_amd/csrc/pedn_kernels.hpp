@@ -13,7 +13,6 @@
 //                     link update still pending under the owner-wave plan: one lane per (corridor = link pair, replica):
 //                     pedestrians, density, fundamental diagram, travel time and its moving average
 //                                                                                       link.py:133-188; functions.py:112-134
-//                     (link_kernel<NS>: the same with two replicas per lane in NS segments of 128 replicas, PEDN_LINK_NS)
 //   link_turn_kernel  the launch behind it otherwise: [turning fractions of t+1, long rows | link update of t, two replicas per
 //                     lane | turning fractions of t+1, short rows | RL observations of t] as independent workgroups
 //   turn_frac_kernel  the turning fractions on their own (first step of an episode): one wave per (row of a dynamic node, 64
@@ -109,8 +108,9 @@ struct SlotIn {
 // Link.cal_sending_flow (link.py:216-370) incl. get_outflow (:199-214) for t' >= free_flow_tau
 // ci_look = cumulative_inflow[max(0, t' + 1 - tau)] of the link, loaded by the caller (tau from x.att_in as below) so that the load is
 // in flight while the caller draws the receiving side's binomial
+// vhi: DevView.valid_hi as it stands for THIS step (the host's value, or the device clock's -- see node_kernel)
 template <bool HIST>
-__device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, double ci_look, uint32_t& fl) {
+__device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int r, const SlotIn& x, double ci_look, const int vhi, uint32_t& fl) {
   const int RS = v.RS, T1 = v.T1;
   const float nself = x.n_in, nrev = x.n_out, kk = x.k_in, att = x.att_in;
   float dens = P.sep ? kk : (nself + nrev) / P.area32;
@@ -135,7 +135,7 @@ __device__ double send_flow(const DevView& v, const LinkP& P, int l, int tp, int
       i0 = in[at(w0, l, v.Lall, RS, r)], i1 = in[at(w1, l, v.Lall, RS, r)];
       i2 = in[at(w2, l, v.Lall, RS, r)], i3 = in[at(w3, l, v.Lall, RS, r)];
       // lazy reset: a wrapped index lands in a row of the FUTURE, which holds the last episode's value instead of the untouched 0
-      i0 = w0 > v.valid_hi ? 0.0 : i0; i1 = w1 > v.valid_hi ? 0.0 : i1; i2 = w2 > v.valid_hi ? 0.0 : i2; i3 = w3 > v.valid_hi ? 0.0 : i3;
+      i0 = w0 > vhi ? 0.0 : i0; i1 = w1 > vhi ? 0.0 : i1; i2 = w2 > vhi ? 0.0 : i2; i3 = w3 > vhi ? 0.0 : i3;
     }
     // Philox call 0 of the sending binomial needs no data: drawn while the four loads are in flight
     uint32_t w[4] = {0u, 0u, 0u, 0u};
@@ -519,16 +519,10 @@ __device__ __forceinline__ void turn_frac_body(const DevView& v, int t, unsigned
     // the record behind the row's last group belongs to another row: size 0, evaluated on harmless values, nothing stored
     const int na = rdl(gcur, 0), nb = 2 * pi + 1 < n_grp ? rdl(gcur, 32) : 0;
     const int nmax = max(na, nb);
-    // -DPEDN_LT_LEAN (diagnostic build, with -DPEDN_TF_LDS_ROWS=40): ONE softmax group at a time and link_turn_kernel held to 6 waves per
-    // SIMD -- 80 VGPRs (84-100 B of scratch), 24 KB of LDS, six workgroups per CU.  Measured: delft x 1024 two chains
-    // 43.4 -> 49.5 us per step, one chain 49.1 -> 51.7, RL step 25.3 -> 30.6 (profiles/r04_lean_link_turn.txt): the launch is as long as
-    // its longest rows' chains, which the side-by-side evaluation halves; more resident workgroups do not buy that back.
-#ifndef PEDN_LT_LEAN
+    // (one softmax group at a time at 80 VGPRs / six workgroups per CU was measured slower: profiles/r04_lean_link_turn.txt)
     if (nmax <= 2 && !(v.tf_general & 1)) eval_pair(std::integral_constant<int, 2>{}, gcur, na, nb);
     else if (nmax <= 3 && !(v.tf_general & 1)) eval_pair(std::integral_constant<int, 3>{}, gcur, na, nb);
-    else
-#endif
-    { (void)nmax; eval_slow(gcur, 0, na); eval_slow(gcur, 32, nb); }
+    else { eval_slow(gcur, 0, na); eval_slow(gcur, 32, nb); }
     gcur = gnext;
   }
   TPH(2, lane);
@@ -717,11 +711,9 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 }
 
 // One block = 8 waves = a bin of nodes whose slot counts add up to <= 8; one wave per (node slot, 64 replicas).
-// WAVES = waves per SIMD the register allocation aims at.  8 (the default): 59..63 VGPRs, no vector spill, about 20 scalar
-// registers spilled into VGPR lanes, 4 blocks per CU.  6 (PEDN_NODE_WAVES=6, a diagnostic): no spill of any kind, but 94 scalar
-// registers leave 7 waves per SIMD -- slower on every model measured -- except with per-replica link
-// parameters (PR: 28 more live vector registers), where 6 is the default (0 spills instead of 2..8).  tests/test_kernel_resources.py
-// guards the budget: one more live register in the wrong place turns the scalar spills into 16 vector spills (+11 us).
+// Register budget: node_kernel_waves() below.  At 8 waves per SIMD: 59..63 VGPRs, no vector spill, scalar registers spilled into VGPR
+// lanes, 4 blocks per CU.  tests/test_kernel_resources.py guards the budget (no scratch, no vector spill): one more live register in
+// the wrong place turns the scalar spills into 16 vector spills (+11 us).
 // LP: the node model is the linear programme of assign_flows_type 'optimal' instead of the classic proportional rule.
 // MD: degree the row / column loops and the row of turning fractions are unrolled for (the host picks 6 when no node of the
 // model has more incident corridors: 4 vector registers less in a kernel that lives on its last one)
@@ -736,14 +728,13 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // TF (with LU; the single-launch plan of small batches with dynamic turning fractions): a slot wave whose row of fractions is computed
 // on the device computes it ITSELF (turn_frac_body<.., INL>: from num_pedestrians[t-2] and the flows of t-1, the arithmetic the second
 // launch of step t-1 would have used), right behind its batch of loads -- no launch in front of or behind node_kernel.
-// node_step: one step of one workgroup (bx = replica group, by = bin of nodes); node_kernel = one step per launch, node_persist_kernel
-// = a range of steps per launch (below).
+// node_step: one step of one workgroup (bx = replica group, by = bin of nodes).
 // HELP (with TF; node_kernel_h, workgroups of SIXTEEN waves): waves 8..15 are helpers -- helper 8 + k computes the row of fractions of
 // slot wave k (where that wave would compute its own) while the slot wave does its loads, link update and flows; they meet once, right
 // before the slot wave multiplies its row into the sending flow.  A step of a small batch is as long as its slowest wave's chain: the
 // row (~5 us) and the rest (~5 us) side by side instead of in a row.
 template <bool PR, bool LP, bool HIST, int MD, bool LU, bool TF, bool HELP = false>
-__device__ __forceinline__ void node_step(const DevView& v, const int t, const int bx, const int by, double* const pedn_lds) {
+__device__ __forceinline__ void node_step(const DevView& v, const int t, const int vhi, const int bx, const int by, double* const pedn_lds) {
   double* const sR = pedn_lds;                          // [8][64] receiving flow of each wave's outgoing link
   double* const sS = pedn_lds + 8 * 64;                 // [8][64] LP only: sending flow of each wave's incoming link
   double* const sPS = pedn_lds + (LP ? 16 : 8) * 64;    // per node m*m tiles of 64 lanes: P[i][j]*s_i, then floor(g_ij)
@@ -865,7 +856,7 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
       r_i = 1e6;
     } else {
       if (!TF) load_batch();
-      x.co_sw = t_sw > v.valid_hi ? 0.0 : x.co_sw;   // as for ci_look below
+      x.co_sw = t_sw > vhi ? 0.0 : x.co_sw;   // as for ci_look below
       const double lu_gate = x.back_out;
       if (v.rl_actions != nullptr && W.act >= 0 && r < v.R) {
         // ActionApplier for a gater (rl/builders.py:313-352: clip_gater_action_value + back_gate_width setter, link.py:121-126),
@@ -895,10 +886,12 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
         // Network.update_link_states(t') for the incoming link (link.py:133-188); the speed noise needs none of the loads
         const double nz = speed_noise(v, Pin, lin, tp, r);
         const float na = (float)((double)lu_pa + (lu_ia - lu_oa)), nb = (float)((double)lu_pb + (lu_ib - lu_ob));  // link.py:133-135
-        const double wa = Pin.sep ? x.sepw_in : Pin.width, wb = Pout.sep ? x.sepw_out : Pout.width;
-        // a separator width held as np.float64 turns the division into binary64 (PEDN_W_SEP_NUMPY), see link_update_one
-        const float ka = (Pin.sep && lu_npa != 0.0) ? (float)((double)na / (Pin.length * wa)) : na / (float)(Pin.length * wa);
-        const float kb = (Pout.sep && lu_npb != 0.0) ? (float)((double)nb / (Pout.length * wb)) : nb / (float)(Pout.length * wb);
+        // density = num_pedestrians / float32(length * width) (link.py:136): a plain link's area is the record's area32 -- bit for bit the
+        // same cast, and length / width need not stay in scalar registers; a separator divides by its current width, in binary64 when
+        // that width is held as np.float64 (PEDN_W_SEP_NUMPY), see link_update_one
+        float ka = na / Pin.area32, kb = nb / Pout.area32;
+        if (Pin.sep) ka = lu_npa != 0.0 ? (float)((double)na / (Pin.length * x.sepw_in)) : na / (float)(Pin.length * x.sepw_in);
+        if (Pout.sep) kb = lu_npb != 0.0 ? (float)((double)nb / (Pout.length * x.sepw_out)) : nb / (float)(Pout.length * x.sepw_out);
         const SpeedOut so = speed_calc(v, Pin, lin, tp, r, ka, kb, lu_rs, lu_old, nz);
         rowp(v.f32[G_N], R32(G_N, tp), lin, L, RS, r0)[lane] = na;
         rowp(v.f32[G_K], R32(G_K, tp), lin, L, RS, r0)[lane] = ka;
@@ -923,9 +916,9 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
       if (idx_s > tp + 1) idx_s = tp + 1;   // a zero / negative / garbage avg_travel_time must not take the load past the rows written so far
       double ci_look = v.f64[F_CI][at(R64(F_CI, idx_s), lin, Lall, RS, r)];
       // (lazy reset: a zero look-back -- the PEDN_F_SAME_STEP case -- reads the row of THIS step, which an ordinary reset left at 0)
-      ci_look = idx_s > v.valid_hi ? 0.0 : ci_look;
+      ci_look = idx_s > vhi ? 0.0 : ci_look;
       const double rp = recv_reverse_peds(v, Pout, lout, tp, r, x, fl);
-      s_i = early ? 0.0 : send_flow<HIST>(v, Pin, lin, tp, r, x, ci_look, fl);
+      s_i = early ? 0.0 : send_flow<HIST>(v, Pin, lin, tp, r, x, ci_look, vhi, fl);
       PH(3, s_i);
       rowp(v.f64[F_S], R64(F_S, tp), lin, L, RS, r0)[lane] = s_i;  // link.py:268,367
       if (s_i < 0.0) fl |= PEDN_F_NEG_FLOW;
@@ -1039,81 +1032,54 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
 #endif
 }
 
-template <bool PR, int WAVES, bool LP, bool HIST, int MD = PEDN_MAX_DEGREE, bool LU = false, bool TF = false>
-__global__ __launch_bounds__(512, WAVES) void node_kernel(DevView v, int t) {
+// Register budget of node_kernel = waves per SIMD its allocation aims at: 8 with shared link parameters and at most 6 corridors per
+// node (59..63 VGPRs, no vector spill); 6 with per-replica parameters (28 more live vector registers: 0 spills instead of 2..8), for
+// a node of 7 or 8 corridors (the instantiation unrolled for 8: 4..8 vector spills at 8 waves, none at 6) and for the node LP (4..14
+// vector spills at 8); 2 where the slot waves compute their own rows of turning fractions (one workgroup per CU).  The other budgets
+// were built and measured slower on every model (profiles/EXPERIMENTS.md #15, #24, #44).
+// CLK (the clocked env step, below): 6 -- the step index and valid_hi are values loaded from memory that stay live, and at 8 waves the
+// allocator answers with 20 vector spills; the batched RL step never fills the wave places of 8 anyway (544 workgroups at 2048 envs).
+template <bool PR, bool LP, int MD, bool TF, bool CLK = false>
+constexpr int node_kernel_waves() { return TF ? 2 : (LP || PR || MD > 6 || CLK) ? 6 : 8; }
+
+// The step index of a launch: the host's argument, or -- CLK, the device clock (pedn_rl_clock_begin / pedn_rl_step_clocked: an env step
+// whose launches have CONSTANT arguments, so that a captured graph can be replayed) -- read from v.clock:
+//   clock[0]  step the next node_kernel runs      clock[1]  step the launch behind it runs (written by node_kernel)
+//   clock[2]  DevView.valid_hi for that node_kernel (lazy reset: rows above it hold the previous episode's values)
+// node_kernel(t) hands t to its second launch; that launch's first workgroup advances clock[0] / clock[2] when every read of them is
+// over (stream order: no launch reads a word that the launch running next to it writes).
+// The clocked launches are instantiations of their own (CLK): a step index that is a kernel argument can be re-read from the argument
+// segment wherever it is needed, one that was loaded from memory has to be held in scalar registers, and node_kernel has none to spare.
+struct StepClock { int t, vhi; };
+__device__ __forceinline__ StepClock node_clock(const DevView& v) {
+  StepClock c;
+  c.t = v.clock[0];   // wave-uniform: two scalar loads beside the slot record's
+  c.vhi = v.clock[2];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) v.clock[1] = c.t;
+  return c;
+}
+
+template <bool PR, bool LP, bool HIST, int MD = PEDN_MAX_DEGREE, bool LU = false, bool TF = false, bool CLK = false>
+__global__ __launch_bounds__(512, (node_kernel_waves<PR, LP, MD, TF, CLK>())) void node_kernel(DevView v, int t) {
   // dynamic LDS, sized by the host for the fullest block (pedn_create: node_lds): a block of nodes of degree 3..4 needs 24 of
   // the 64 tiles a single degree-8 node would
   // blockIdx.x = replica group (fastest in dispatch order): blocks launched together touch neighbouring 512-byte chunks
   // of the same history rows
   extern __shared__ double pedn_lds[];
-  node_step<PR, LP, HIST, MD, LU, TF>(v, t, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
+  if (CLK) {
+    const StepClock c = node_clock(v);
+    if (c.t >= v.T1) return;   // a clocked launch replayed beyond the horizon: uniform over the grid
+    node_step<PR, LP, HIST, MD, LU, TF>(v, c.t, c.vhi, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
+  } else {
+    node_step<PR, LP, HIST, MD, LU, TF>(v, t, v.valid_hi, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
+  }
 }
 
 // the single-launch plan with helper waves (node_step<.., HELP>): sixteen waves per workgroup, 128 vector registers each
 template <bool PR, bool HIST, int MD>
 __global__ __launch_bounds__(1024) void node_kernel_h(DevView v, int t) {
   extern __shared__ double pedn_lds[];
-  node_step<PR, false, HIST, MD, true, true, true>(v, t, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
-}
-
-// Persistent plan of small networks (pedn_run; network.py:266-287 for a RANGE of steps): steps [t0, t1) in ONE launch.  Replicas are
-// independent, and under the owner-wave / single-launch plan a step reads nothing that the same step writes -- so the n_bins workgroups
-// of a replica group only have to meet between steps.  They meet at a counter, and they all run on ONE XCD (workgroups go to the XCDs
-// round robin by their index: group g's workgroups have indices = g mod 8), so that what they exchange through the history rows never
-// has to leave that XCD's L2: before a workgroup arrives every wave has waited for the L2's acknowledgement of its stores (s_waitcnt
-// vmcnt(0) -- the vector L1 is write-through), after it leaves every wave drops its L1 (buffer_inv sc1; device memory is cached RW
-// in the L2 and is not touched by it).  No L2 write-back (what an agent-scope release would do: 17-80 us per round, round 3).
-// The placement is CHECKED: the first workgroup of a group publishes its XCC id, any other that finds a different one raises
-// PEDN_F_PLACEMENT for the group's replicas (results invalid).  A workgroup that waits longer than ~1 s raises the same flag and leaves:
-// every wave reaches the end of the kernel whatever happens.
-// MEASURED NEGATIVE (profiles/r04_persistent_step.txt), hence opt-in (PEDN_PERSIST=1): a step of a small network is the serial
-// chain of ONE wave (its row of fractions, its dependent loads, its binomials: 13 of nine_intersections' 16 us), not the launch gap --
-// the meeting alone costs 1.5-2.5 us per step, the L1 invalidate another 0.7-1.5 (it is needed: tools/l1_inv_probe.hip shows a stale
-// line surviving `buffer_inv sc0`; only sc1 drops it), and a launch per step is 16.2 us against 16.8 here.
-// -DPEDN_PERSIST_EXP=1: without the invalidate, =2: the meeting alone -- TIMING ONLY, the numbers are wrong.
-// bar: per replica group 32 words (one 128-byte line): [0] arrivals (monotonic over launches: `base` = its value before this one),
-// [1] XCC id of the group (0xffffffff before the first launch).
-template <bool PR, int WAVES, bool HIST, int MD, bool TF>
-__global__ __launch_bounds__(512, WAVES) void node_persist_kernel(DevView v, int t0, int t1, unsigned* bar, unsigned base, int n_bins, int rgroups) {
-  extern __shared__ double pedn_lds[];
-  __shared__ int s_dead;
-  const unsigned q = blockIdx.x >> 3;
-  const int by = (int)(q % (unsigned)n_bins);
-  const int bx = (int)(q / (unsigned)n_bins) * 8 + (int)(blockIdx.x & 7u);
-  if (bx >= rgroups) return;   // workgroup-uniform: the padding of the last eight groups
-  unsigned* const cnt = bar + (size_t)bx * 32;
-  if (threadIdx.x == 0) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 15u;
-    const unsigned seen = atomicCAS(&cnt[1], 0xffffffffu, xcc);
-    s_dead = (seen != 0xffffffffu && seen != xcc) ? 1 : 0;
-  }
-  for (int t = t0; t < t1; ++t) {
-#if !defined(PEDN_PERSIST_EXP) || PEDN_PERSIST_EXP != 2
-    node_step<PR, false, HIST, MD, true, TF>(v, t, bx, by, pedn_lds);
-#endif
-    if (t + 1 == t1) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are in the L2
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a misplaced workgroup still arrives: the others do not wait for it)
-      const unsigned target = base + (unsigned)n_bins * (unsigned)(t - t0 + 1);
-      int spins = 0;
-      while (!s_dead && (int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 21)) { s_dead = 1; break; }
-      }
-    }
-    __syncthreads();
-    if (s_dead) {   // workgroup-uniform
-      if (threadIdx.x < 64 && bx * 64 + (int)threadIdx.x < v.RS) atomicOr(&v.flags[bx * 64 + threadIdx.x], PEDN_F_PLACEMENT);
-      return;
-    }
-#if !defined(PEDN_PERSIST_EXP) || PEDN_PERSIST_EXP != 1
-    asm volatile("buffer_inv sc1" ::: "memory");       // nothing stale in this CU's L1
-#endif
-  }
+  node_step<PR, false, HIST, MD, true, true, true>(v, t, v.valid_hi, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
 }
 
 __device__ __forceinline__ double2 ld2(const double* p, size_t i) { return *reinterpret_cast<const double2*>(p + i); }
@@ -1121,12 +1087,13 @@ __device__ __forceinline__ float2 ld2(const float* p, size_t i) { return *reinte
 __device__ __forceinline__ void st2(double* p, size_t i, double a, double b) { *reinterpret_cast<double2*>(p + i) = make_double2(a, b); }
 __device__ __forceinline__ void st2(float* p, size_t i, float a, float b) { *reinterpret_cast<float2*>(p + i) = make_float2(a, b); }
 
-// Network.update_link_states (network.py:257-264).  One lane = both directions of one corridor for two adjacent replicas in
-// each of NS segments of 128 replicas: every history access is a 16-byte (f64) or 8-byte (f32) vector access, i.e. 1 KiB /
-// 512 B contiguous per wave instruction.  NS = 2 halves the number of waves for the same work (twice the loads in flight per
-// wave): used inside link_turn_kernel, where the turning-fraction waves compete for the wave slots.
-template <int NS, bool HIST>
+// Network.update_link_states (network.py:257-264).  One lane = both directions of one corridor for two adjacent replicas of a
+// segment of 128 replicas: every history access is a 16-byte (f64) or 8-byte (f32) vector access, i.e. 1 KiB / 512 B contiguous
+// per wave instruction.  Used inside link_turn_kernel, where the turning-fraction waves compete for the wave slots (half the
+// waves of link_pr_body).  (Two segments per lane -- four replicas -- were measured slower, profiles/r03_link_kernel_variants.txt.)
+template <bool HIST>
 __device__ __forceinline__ void link_body(const DevView& v, int t, size_t gid) {
+  constexpr int NS = 1;
   const int RS = v.RS, L = v.L, Lall = v.Lall, H = v.subRS / (2 * NS);  // lanes per corridor
   int p = __builtin_amdgcn_readfirstlane((int)(gid / (size_t)H));
   const int lh = (int)(gid % (size_t)H);
@@ -1250,8 +1217,8 @@ __device__ __forceinline__ void link_update_one(const DevView& v, const LinkP& P
   if (gb != Pb.width || v.hist) v.f64[F_GATE][at(R64(F_GATE, t), b, L, RS, r)] = gb;
 }
 
-// Same update with ONE replica per lane: with per-replica link parameters (PR: they live in vector registers), or with the shared
-// record (PEDN_LINK_NS=0, a diagnostic: twice the waves of link_body<1> at ~45 instead of 69 vector registers, 8-byte accesses).
+// Same update with ONE replica per lane: with per-replica link parameters (PR: they live in vector registers), and as the launch of
+// its own over shared parameters (link_kernel_1r: twice the waves of link_body at ~45 instead of 69 vector registers, 8-byte accesses).
 template <bool PR, bool HIST>
 __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid) {
   const int RS = v.RS, L = v.L, Lall = v.Lall;
@@ -1266,8 +1233,6 @@ __device__ __forceinline__ void link_pr_body(const DevView& v, int t, size_t gid
                         v.f32[G_N][at(R32(G_N, t - 1), a, L, RS, r)], v.f32[G_N][at(R32(G_N, t - 1), b, L, RS, r)]);
 }
 
-template <int NS, bool HIST>
-__global__ __launch_bounds__(256) void link_kernel(DevView v, int t) { link_body<NS, HIST>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
 template <bool PR, bool HIST>
 __global__ __launch_bounds__(256) void link_kernel_1r(DevView v, int t) { link_pr_body<PR, HIST>(v, t, (size_t)blockIdx.x * blockDim.x + threadIdx.x); }
 
@@ -1437,20 +1402,23 @@ __global__ __launch_bounds__(256) void rl_observe_kernel(DevView v, RlView q, in
 // when the first workgroups retire: with every turning-fraction workgroup in front, a third of the link update started only after
 // the short rows had finished and ended long after the long rows (delft x 1024: 20.8 us for 12 us of critical path).
 // (OBS = false: the instantiation ordinary stepping uses carries neither the LDS nor the registers of the third part)
-template <bool PR, bool OBS, int NS, bool HIST>
-__global__
-#ifdef PEDN_LT_LEAN
-__launch_bounds__(256, 6)
-#else
-__launch_bounds__(256, 4)
-#endif
-void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, unsigned n_tp_heavy, RlView q,
+template <bool PR, bool OBS, bool HIST, bool CLK = false>
+__global__ __launch_bounds__(256, 4) void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_blocks, unsigned n_tp_heavy, RlView q,
                                                            int accumulate) {
   // one LDS buffer for whichever part this workgroup is (the observation part needs 6 KB of the turning fractions' 35.5 KB)
   __shared__ double lds[PEDN_TF_LDS_DOUBLES];
   static_assert(sizeof(double) * PEDN_TF_LDS_DOUBLES >= sizeof(float) * PEDN_OBS_LDS_FLOATS, "observation rows must fit");
   // role of this workgroup (one call site per part: each is inlined once)
   const unsigned b = blockIdx.x;
+  if (CLK) {   // device clock (see node_clock): this launch runs the step node_kernel left in clock[1]
+    t = v.clock[1];
+    if (t >= v.T1) return;   // replayed beyond the horizon: node_kernel did nothing either, the clock stays
+    if (b == 0 && threadIdx.x == 0) {   // ... and its first workgroup advances the clock for the next node_kernel
+      const int vh = v.clock[2];
+      v.clock[0] = t + 1;
+      v.clock[2] = (vh != 0x7fffffff && t > vh) ? t : vh;   // launch_step's bookkeeping: rows <= t are written once this step's launches are
+    }
+  }
   const bool is_tp = b < n_tp_heavy || (b >= n_tp_heavy + n_link_blocks && b < n_tp_blocks + n_link_blocks);
 #ifdef PEDN_PHASE_PROFILE
   if (threadIdx.x == 0 && b < PEDN_LT_BLOCKS) {
@@ -1459,11 +1427,12 @@ void link_turn_kernel(DevView v, int t, unsigned n_link_blocks, unsigned n_tp_bl
   }
 #endif
   if (is_tp) {
-    turn_frac_body<PR, true, HIST>(v, t + 1, b < n_tp_heavy ? b : b - n_link_blocks, lds);
+    // (behind the last step of the horizon there is no step t + 1: the host launches no such workgroups, a clocked launch has them idle)
+    if (t + 1 < v.T1) turn_frac_body<PR, true, HIST>(v, t + 1, b < n_tp_heavy ? b : b - n_link_blocks, lds);
   } else if (b < n_tp_heavy + n_link_blocks) {
     const size_t gid = (size_t)(b - n_tp_heavy) * blockDim.x + threadIdx.x;
     if (PR) link_pr_body<true, HIST>(v, t, gid);
-    else link_body<NS, HIST>(v, t, gid);
+    else link_body<HIST>(v, t, gid);
   } else if (OBS) {
     rl_observe_body<true, HIST>(v, q, t, accumulate, b - n_link_blocks - n_tp_blocks, reinterpret_cast<float*>(lds));
   }
@@ -1763,8 +1732,10 @@ __global__ void rand_demand_kernel(double* dst, const int32_t* rows, const int32
   dst[(row * T1 + t) * RS + r] = val;
 }
 
-// first work on the engine's second stream (pedn_hip.hip: warm_second_stream)
-__global__ void noop_kernel() {}
+// pedn_rl_clock_begin: the device clock (node_clock) set to step t
+__global__ void set_clock_kernel(int32_t* clock, int t, int valid_hi) {
+  if (threadIdx.x == 0) { clock[0] = t; clock[1] = t; clock[2] = valid_hi; clock[3] = 0; }
+}
 // busy for `ticks` of the constant 100 MHz clock (pedn_hip.hip: probe_overlap); every wave reaches the exit
 __global__ void spin_kernel(unsigned long long ticks) {
   const unsigned long long t0 = wall_clock64();

@@ -113,6 +113,10 @@ struct DevView {
   // look-backs (link.py:205-212: Python's inflow[-k] = the untouched tail = 0): answered with the initial value instead of the row.
   // 0x7fffffff after an ordinary reset.
   int32_t valid_hi;
+  // Device-resident step clock (pedn_rl_clock_begin / pedn_rl_step_clocked): a launch whose step argument is negative takes its step --
+  // and the node kernel its valid_hi -- from here, see node_clock in pedn_kernels.hpp.  [0] node_kernel's step, [1] the step of the
+  // launch behind it, [2] valid_hi.
+  int32_t* clock;
   int32_t tf_lds_off;   // node_kernel<.., TF>: first double of the waves' private LDS rows for their own turning fractions (PEDN_TF_INL_ROWS each)
   int32_t pairs_adj;  // 1: corridor p is the links (2p, 2p + 1) -- the reference creates the two directions of an edge one after the other --
                       // so the link update forms its row addresses from p alone, without waiting for the corridor's record

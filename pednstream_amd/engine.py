@@ -12,14 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PEDN_HIP_LIB") or os.path.join(_HERE, "csrc", "libpedn_hip.so")   # env override: A/B builds
 
 PEDN_ALL = -1
-ABI_VERSION = 3
+ABI_VERSION = 4
 ERROR_BITS = {1: "negative sending flow (ValueError, link.py:345-346,365-366)",
               2: "negative flows at a node (Warning, node.py:192-194,218-219,237-238)",
               4: "history index out of range (IndexError)",
               8: "binomial with n < 0 (ValueError, link.py:382)",
               16: "zero-step look-back: result depends on node iteration order in the reference",
-              32: "node LP (assign_flows_type 'optimal') did not terminate",
-              64: "persistent plan: a replica group's workgroups did not share an XCD or did not all arrive (opt-in plan, PEDN_PERSIST=1)"}
+              32: "node LP (assign_flows_type 'optimal') did not terminate"}
 
 _I32P, _F64P, _F32P = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float)
 
@@ -167,6 +166,11 @@ def _load():
         "pedn_rl_observe": (C.c_int, [P, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
         "pedn_rl_step": (C.c_int, [P, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
         "pedn_rl_device_ptr": (C.c_void_p, [P, C.c_int32]),
+        "pedn_rl_clock_begin": (C.c_int, [P, C.c_int32]),
+        "pedn_rl_step_clocked": (C.c_int, [P, C.c_void_p, C.c_int32, C.c_void_p]),
+        "pedn_rl_clock_end": (C.c_int, [P, C.POINTER(C.c_int32)]),
+        "pedn_rl_clocked": (C.c_int, [P]),
+        "pedn_flush": (C.c_int, [P]),
         "pedn_device_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _F64P, _F64P, C.c_uint64, _F64P]),
     }
     # the version first: a stale or alternate library (PEDN_HIP_LIB) must fail with this message, not with an AttributeError on a symbol
@@ -195,7 +199,8 @@ EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
            "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_reset_lazy", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_plan_info", "pedn_rl_configure",
            "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
-           "pedn_set_od_weights_per_replica", "pedn_get_od_weights_per_replica", "pedn_get_link_params", "pedn_randomize_scenarios", "pedn_reset_widths"]
+           "pedn_set_od_weights_per_replica", "pedn_get_od_weights_per_replica", "pedn_get_link_params", "pedn_randomize_scenarios", "pedn_reset_widths",
+           "pedn_flush", "pedn_rl_clock_begin", "pedn_rl_step_clocked", "pedn_rl_clock_end", "pedn_rl_clocked"]
 
 
 def _p(a, dtype=np.float64):
@@ -437,11 +442,11 @@ class Engine:
         info = np.zeros(5, dtype=np.int32)
         self._ck(self._lib.pedn_plan_info(self._h, info.ctypes.data_as(_I32P), 5))
         return {"chains": int(info[0]), "link_update_by_next_node_kernel": bool(info[1]), "stream_probe_attempts": int(info[2]),
-                "stream_probe_us": int(info[3]), "persistent_ranges": bool(info[4])}
+                "stream_probe_us": int(info[3])}
 
     def set_streams(self, n):
-        """Launch plan of run() for long ranges: 1 chain of launches, or 2 / 4 (the halves / quarters of the replica batch on as many
-        streams; falls back to what the runtime's hardware queues allow -- see plan_info())."""
+        """Launch plan of run() for long ranges: 1 chain of launches, or 2 (the halves of the replica batch on two streams; falls
+        back to one when the runtime's hardware queues do not run them side by side -- see plan_info())."""
         self._ck(self._lib.pedn_set_streams(self._h, int(n)))
 
     # -- batched RL glue
@@ -496,6 +501,28 @@ class Engine:
         observations and rewards stay in the device buffers (``rl_device_ptr``).  ordered: every launch on ``stream_ptr()`` (for a
         caller that chains the call to its own streams with events)."""
         self._ck(self._lib.pedn_rl_step(self._h, C.c_void_p(int(actions_ptr)), 2 if ordered else 1, int(t), int(action_gap), None, None))
+
+    def rl_clock_begin(self, t):
+        """The device-resident step clock set to step t (include/pedn.h: pedn_rl_clock_begin); the fractions of t must be prepared."""
+        self._ck(self._lib.pedn_rl_clock_begin(self._h, int(t)))
+
+    def rl_step_clocked(self, actions_ptr, action_gap=1, stream_ptr=0):
+        """One env step with constant launch arguments on ``stream_ptr`` (0: the engine's stream); safe under stream capture."""
+        self._ck(self._lib.pedn_rl_step_clocked(self._h, C.c_void_p(int(actions_ptr)) if actions_ptr else None, int(action_gap),
+                                                C.c_void_p(int(stream_ptr)) if stream_ptr else None))
+
+    def rl_clocked(self):
+        return bool(self._lib.pedn_rl_clocked(self._h))
+
+    def rl_clock_end(self):
+        """Ends the clocked section (synchronises the device); returns the next step to run."""
+        t = C.c_int32(0)
+        self._ck(self._lib.pedn_rl_clock_end(self._h, C.byref(t)))
+        return int(t.value)
+
+    def flush(self):
+        """Everything pending enqueued on the engine's stream (pedn_flush): zero-copy consumers behind ``stream_ptr()`` see complete rows."""
+        self._ck(self._lib.pedn_flush(self._h))
 
     def stream_ptr(self):
         """hipStream_t of the engine (``pedn_stream``), e.g. for ``torch.cuda.ExternalStream``."""

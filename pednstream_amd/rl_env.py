@@ -306,12 +306,36 @@ class VecPedNetEnv:
         self.sim_step += self.action_gap
         self.network.current_step = self.sim_step - 1
         self.network._widths_stale = True
+        obs, rew = self.device_views()
+        return obs, rew, (self.sim_step - 1) >= self.simulation_steps
+
+    def device_views(self):
+        """(obs [n_envs, n_obs], rewards [n_envs, n_agents]): float32 torch tensors that ALIAS the engine's device buffers."""
         if self._device_views is None:
+            import torch
+
+            eng = self.network.engine()
             dev = torch.device("cuda", self.network.device)
             view = lambda which, cols: torch.as_tensor(_DeviceBuffer(eng.rl_device_ptr(which), (self.n_envs, cols), "<f4"), device=dev)
             self._device_views = (view(1, self.n_obs), view(2, len(self.possible_agents)))
-        obs, rew = self._device_views
-        return obs, rew, (self.sim_step - 1) >= self.simulation_steps
+        return self._device_views
+
+    def capture(self, policy_fn, on_step=None, generators=()):
+        """A graph-replayable rollout loop: ``policy_fn(obs) -> actions`` (torch ops only; obs is the engine's float32 observation buffer
+        [n_envs, n_obs], actions a contiguous float64 CUDA tensor [n_envs, n_actions]) followed by one env step and ``on_step(obs, rewards)``
+        (optional, torch ops only: reward bookkeeping, storing the transition) captured ONCE as a ``torch.cuda.CUDAGraph`` and replayed
+        per policy step -- see ``GraphedRollout``.  ``generators``: every ``torch.Generator`` the two callables draw from other than the
+        default one (torch must know them before the capture: ``CUDAGraph.register_generator_state``)."""
+        return GraphedRollout(self, policy_fn, on_step, generators)
+
+    def _ordered_behind_engine(self):
+        """The caller's current torch stream waits (on the device) for everything enqueued on the engine's stream so far."""
+        import torch
+
+        dev = torch.device("cuda", self.network.device)
+        if self._ext_stream is None:
+            self._ext_stream = torch.cuda.ExternalStream(self.network.engine().stream_ptr(), device=dev)
+        torch.cuda.current_stream(dev).wait_stream(self._ext_stream)
 
     def gather_device(self, total_envs=None):
         """Observations and rewards of ALL ranks' envs after ``step_device``: (obs [n_envs_total, n_obs], rewards
@@ -329,6 +353,94 @@ class VecPedNetEnv:
 
     def close(self):
         self.network.close()
+
+
+class GraphedRollout:
+    """Config #5 the way BASELINE words it -- the env FEEDING a policy (rl/pz_pednet_env.py:195-254 is called once per policy step,
+    rl/train_ppo_sb3.py:246) -- without the host in the loop: one iteration = policy forward -> env step -> ``on_step`` is captured
+    once as a ``torch.cuda.CUDAGraph`` and replayed.  What makes the env step replayable is the engine's device-resident step clock
+    (include/pedn.h: pedn_rl_clock_begin / pedn_rl_step_clocked): the step's launches have constant arguments, the step index is read
+    from -- and advanced in -- device memory.
+
+        roll = env.capture(policy_fn, on_step)
+        env.reset()
+        while not roll.step(): pass          # one policy step per call; True when the episode is over
+
+    The first step of an episode runs eagerly (its stand-alone turning fractions read the gate widths behind that step's actions, which
+    only the ordinary step orders); so does a step after anything else touched the engine (``env.step``, a setter, a read): the rollout
+    notices (``pedn_rl_clocked``) and begins a new clocked section.  The same numbers as ``step_device`` step for step
+    (tests/test_gpu_rl.py)."""
+
+    def __init__(self, env, policy_fn, on_step=None, generators=()):
+        import torch
+
+        self.env, self.policy_fn, self.on_step, self.generators = env, policy_fn, on_step, tuple(generators)
+        self.dev = torch.device("cuda", env.network.device)
+        self.obs, self.rew = env.device_views()
+        self.graph = None
+        self._actions = None           # the policy's output tensor of the captured iteration (its address is what the graph reads)
+        self.replays = self.eager_steps = 0
+
+    def _iteration(self, stream_ptr):
+        a = self.policy_fn(self.obs)
+        env = self.env
+        if not (a.is_cuda and a.dtype.is_floating_point and a.element_size() == 8 and a.is_contiguous() and tuple(a.shape) == (env.n_envs, env.n_actions)):
+            raise ValueError(f"policy_fn must return a contiguous float64 CUDA tensor of shape {(env.n_envs, env.n_actions)}")
+        env.network.engine().rl_step_clocked(a.data_ptr(), env.action_gap, stream_ptr)
+        if self.on_step is not None:
+            self.on_step(self.obs, self.rew)
+        return a
+
+    def step(self):
+        """One policy step for every env; returns True when the episode is over (``env.reset()`` next)."""
+        import torch
+
+        env = self.env
+        if env.sim_step + env.action_gap - 1 > env.simulation_steps:
+            raise IndexError("episode is over; call reset()")
+        eng = env.network._flush() if not env.network.engine().rl_clocked() else env.network.engine()
+        with torch.cuda.device(self.dev):
+            if not eng.rl_clocked():
+                begun = False
+                if env.sim_step > 1:
+                    try:
+                        eng.rl_clock_begin(env.sim_step)
+                        begun = True
+                    except RuntimeError:
+                        begun = False          # the fractions of this step are not prepared (a setter came in between): one eager step
+                if not begun:
+                    a = self.policy_fn(self.obs)
+                    _, _, done = env.step_device(a, sync=False)
+                    if self.on_step is not None:
+                        self.on_step(self.obs, self.rew)
+                    self.eager_steps += 1
+                    if not done:
+                        eng.rl_clock_begin(env.sim_step)
+                        env._ordered_behind_engine()
+                    return done
+                env._ordered_behind_engine()
+            if self.graph is None:
+                self._capture()
+            self.graph.replay()
+        self.replays += 1
+        env.sim_step += env.action_gap
+        env.network.current_step = env.sim_step - 1
+        env.network._widths_stale = True
+        return (env.sim_step - 1) >= env.simulation_steps
+
+    def _capture(self):
+        import torch
+
+        # (no warm-up calls of policy_fn here: they would advance whatever state the policy keeps.  The eager step every episode starts
+        # with has already run it once, so what torch sets up lazily exists.)
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        g = torch.cuda.CUDAGraph()
+        for gen in self.generators:
+            g.register_generator_state(gen)
+        with torch.cuda.graph(g, stream=side):  # recorded, not run: the env does not advance
+            self._actions = self._iteration(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.graph = g
 
 
 class PedNetParallelEnv:

@@ -173,7 +173,10 @@ class ScenarioBatch:
         net = self.net
         eng = net._flush()
         origins = [node for node in net.nodes.values() if node.virtual_incoming_link is not None and node.node_id in net.origin_nodes]
-        eng.randomize_scenarios(0 if seed is None else seed, link_fraction, links=True, od_weights=self._arr["od_w"] is not None,
+        # seed None = fresh entropy every time, like np.random.default_rng(None) in draw_random_host and like the reference, which keeps
+        # consuming its np.random stream (the usual Gym pattern seeds the first reset only): never the same scenario twice
+        self.last_seed = int(np.random.SeedSequence().entropy) & (2 ** 64 - 1) if seed is None else int(seed)
+        eng.randomize_scenarios(self.last_seed, link_fraction, links=True, od_weights=self._arr["od_w"] is not None,
                                 origin_nodes=[node.index for node in origins])
         if int(len(self._pair_links) * link_fraction) > 0:
             self._on_device |= {"kc", "kj", "vf", "fft", "tau_sw", "tt0"}

@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(built):
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/pedn.h but not exported"
     assert sorted(built.EXPORTS) == names, "engine.EXPORTS out of sync with the header"
-    assert lib.pedn_abi_version() == built.ABI_VERSION == 3
+    assert lib.pedn_abi_version() == built.ABI_VERSION == 4
 
 
 def test_ctypes_struct_matches_header_layout(built):

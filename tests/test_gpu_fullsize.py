@@ -48,7 +48,7 @@ def invariants(e, model, steps, r0, r1):
 
 @pytest.mark.parametrize("name,R,steps", [("delft", 1024, 130), ("45_intersections", 2048, 120)])
 def test_full_size_batch_under_the_default_plan(name, R, steps):
-    for k in ("PEDN_STREAMS", "PEDN_FUSE_TP", "PEDN_NODE_WAVES", "PEDN_LINK_NS"):
+    for k in ("PEDN_STREAMS", "PEDN_FUSE_TP", "PEDN_LINK_OWNER", "PEDN_INLINE_TF"):
         assert k not in os.environ, f"{k} is set: this test is about the plan the engine picks by itself"
     np.random.seed(7)
     net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=R, rng_seed=3)

@@ -177,24 +177,21 @@ def test_engine_equals_oracle_on_large_networks(name, replicas, steps):
 @pytest.mark.parametrize("name,steps", [("nine_intersections", 120), ("delft", 40), ("long_corridor", 150)])
 def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
     """The engine picks its launch plan per model: turn probabilities of step t+1 fused into the link update of step t or
-    launched on their own (PEDN_FUSE_TP), node_kernel built for 6 or 8 waves per SIMD (PEDN_NODE_WAVES), unrolled for 6 or 8
-    corridors per node, the stand-alone link update with one / two / four replicas per lane, the workgroup order inside link_turn_kernel.  Every plan,
-    step-by-step stepping with a setter in between (which drops the fused probabilities) and a reset must give the same
-    bits in every field; the stand-alone launch is the one the goldens above pin for large models."""
+    launched on their own (PEDN_FUSE_TP), node_kernel unrolled for 6 or 8 corridors per node (PEDN_NODE_MD: 8 waves per SIMD / 6),
+    the workgroup order inside link_turn_kernel, the owner-wave and single-launch plans.  Every plan, step-by-step stepping with a
+    setter in between (which drops the fused probabilities) and a reset must give the same bits in every field; the stand-alone
+    launch is the one the goldens above pin for large models."""
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
 
-    def history(fuse, waves, stepwise, general="0", lds_limit="64", md="6", link_ns="0", heavy="2", pairs_adj="1", owner="0", inline="0"):
+    def history(fuse, stepwise, general="0", lds_limit="64", md="6", heavy="2", pairs_adj="1", owner="0", inline="0"):
         monkeypatch.setenv("PEDN_INLINE_TF", inline)          # 1: the single-launch plan -- node_kernel<LU, TF>'s slot waves compute their own rows (where the model's rows allow); 2: helper waves do
         monkeypatch.setenv("PEDN_LINK_OWNER", owner)          # 1: pedn_run's owner-wave plan -- node_kernel<LU>(t + 1) performs the link update of t
-        monkeypatch.setenv("PEDN_LU_WAVES", waves)
         monkeypatch.setenv("PEDN_PAIRS_ADJ", pairs_adj)        # 0: the link update takes its two link ids from the corridor's record (models whose
                                                                # directions are not numbered 2p, 2p + 1), 1: from the corridor index where the model allows
         monkeypatch.setenv("PEDN_TF_HEAVY_GROUPS", heavy)      # which rows of dynamic nodes go in front of the link update inside link_turn_kernel
-        monkeypatch.setenv("PEDN_LINK_NS", link_ns)           # stand-alone link update: 0 one replica per lane, 1 | 2 two replicas in 1 | 2 segments
         monkeypatch.setenv("PEDN_FUSE_TP", fuse)
         monkeypatch.setenv("PEDN_NODE_MD", md)                # 8: node_kernel unrolled for 8 corridors per node whatever the model has
-        monkeypatch.setenv("PEDN_NODE_WAVES", waves)
         monkeypatch.setenv("PEDN_TF_GENERAL", general)        # 3: softmax groups and row sums through their general (any-size) paths
         monkeypatch.setenv("PEDN_TF_LDS_LIMIT", lds_limit)    # 1: all but one probability of a row overflow from LDS into HBM
         np.random.seed(7)
@@ -221,23 +218,21 @@ def test_launch_variants_give_identical_histories(name, steps, monkeypatch):
         net.close()
         return out
 
-    ref = history("0", "6", False)
-    for variant in (("1", "6", False), ("0", "8", False), ("1", "8", True), ("1", "8", False, "3", "64"), ("0", "8", False, "1", "1"),
-                    ("1", "8", True, "0", "0"), ("1", "8", False, "0", "64", "8"), ("1", "6", False, "0", "64", "8"),
-                    ("0", "8", False, "0", "64", "6", "1"), ("0", "8", True, "0", "64", "6", "2"), ("1", "8", False, "0", "64", "6", "2"),
-                    ("1", "8", False, "0", "64", "6", "0", "0"), ("1", "8", True, "0", "64", "6", "0", "100"),
-                    ("1", "8", False, "0", "64", "6", "0", "2", "0"), ("0", "8", True, "0", "64", "6", "0", "2", "0"),
-                    ("1", "8", False, "0", "64", "6", "0", "2", "1", "1"), ("1", "6", False, "0", "64", "6", "0", "2", "1", "1"),
-                    ("0", "8", False, "0", "64", "8", "0", "2", "0", "1"), ("1", "6", False, "0", "64", "8", "2", "2", "1", "1"),
+    ref = history("0", False)
+    for variant in (("1", False), ("1", True), ("1", False, "3", "64"), ("0", False, "1", "1"),
+                    ("1", True, "0", "0"), ("1", False, "0", "64", "8"), ("0", True, "0", "64", "8"),
+                    ("1", False, "0", "64", "6", "0"), ("1", True, "0", "64", "6", "100"),
+                    ("1", False, "0", "64", "6", "2", "0"), ("0", True, "0", "64", "6", "2", "0"),
+                    ("1", False, "0", "64", "6", "2", "1", "1"), ("0", False, "0", "64", "8", "2", "0", "1"),
                     # step by step under the owner-wave plan: every network_loading(t) leaves its link update pending, the setter in
                     # between and the reads at the end perform it
-                    ("1", "8", True, "0", "64", "6", "0", "2", "1", "1"), ("0", "6", True, "0", "64", "8", "0", "2", "1", "1"),
+                    ("1", True, "0", "64", "6", "2", "1", "1"), ("0", True, "0", "64", "8", "2", "1", "1"),
                     # the single-launch plan: ranges, single steps, step by step with setters and a reset
-                    ("1", "8", False, "0", "64", "6", "0", "2", "1", "1", "1"), ("1", "8", True, "0", "64", "6", "0", "2", "1", "1", "1"),
-                    ("0", "8", False, "0", "64", "8", "0", "2", "0", "1", "1"),
+                    ("1", False, "0", "64", "6", "2", "1", "1", "1"), ("1", True, "0", "64", "6", "2", "1", "1", "1"),
+                    ("0", False, "0", "64", "8", "2", "0", "1", "1"),
                     # ... with helper waves (node_kernel_h: sixteen waves per workgroup, the second eight compute the rows)
-                    ("1", "8", False, "0", "64", "6", "0", "2", "1", "1", "2"), ("1", "8", True, "0", "64", "6", "0", "2", "1", "1", "2"),
-                    ("0", "8", False, "3", "1", "8", "0", "2", "0", "1", "2")):
+                    ("1", False, "0", "64", "6", "2", "1", "1", "2"), ("1", True, "0", "64", "6", "2", "1", "1", "2"),
+                    ("0", False, "3", "1", "8", "2", "0", "1", "2")):
         got = history(*variant)
         for f in ALL_FIELDS:
             assert np.array_equal(ref[f], got[f]), (variant, f)
@@ -277,68 +272,6 @@ def test_repeated_step_after_imposed_fractions_recomputes_them_under_every_plan(
     assert np.array_equal(seen, seen_ref)
     for f in ALL_FIELDS:
         assert np.array_equal(ref[f], got[f]), f
-
-
-@pytest.mark.parametrize("name,R,steps", [("nine_intersections", 256, 120), ("long_corridor", 64, 150), ("od_flow_example", 3, 100)])
-def test_persistent_plan_gives_identical_histories(name, R, steps, monkeypatch):
-    """PEDN_PERSIST=1 (opt-in; a measured negative, profiles/r04_persistent_step.txt): ranges of pedn_run as ONE launch, the workgroups
-    of a replica group meeting between steps inside one XCD.  Long and short ranges, a single step in between, a lazy reset and a second
-    episode: every field and flag as with a launch per step; the placement check must not fire."""
-    from pednstream_amd import NetworkEnvGenerator
-    from golden_util import DATA
-
-    def history(persist):
-        monkeypatch.setenv("PEDN_PERSIST", persist)
-        np.random.seed(7)
-        net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=R, rng_seed=11)
-        e = net.engine()
-        assert e.plan_info()["persistent_ranges"] == (persist == "1")
-        net.run(1, steps, check=False)
-        first = {f: e.read_block(LINK_FIELDS[f][0], 0, steps) for f in ALL_FIELDS}
-        net.reset(lazy=True)
-        net.run(1, 4, check=False); net.network_loading(4); net.run(5, 9, check=False); net.run(9, steps - 2, check=False)
-        net.run(steps - 2, steps, check=False)
-        rc, flags = e.error_flags()
-        out = (first, {f: e.read_block(LINK_FIELDS[f][0], 0, steps) for f in ALL_FIELDS}, flags.copy())
-        net.close()
-        return out
-
-    ref, got = history("0"), history("1")
-    assert not (got[2] & 64).any()
-    assert np.array_equal(ref[2], got[2])
-    for k in (0, 1):
-        for f in ALL_FIELDS:
-            assert np.array_equal(ref[k][f], got[k][f]), (k, f)
-
-
-@pytest.mark.parametrize("name,steps,owner", [("melbourne", 50, "1"), ("nine_intersections", 90, "0"), ("delft", 30, "0")])
-def test_four_chain_plan_gives_identical_histories(name, steps, owner, monkeypatch):
-    """PEDN_STREAMS=4: the quarters of the batch as four chains of launches on four streams (pedn_set_streams(4)).  Whether the runtime
-    gives the four streams hardware queues of their own only decides how fast this is (the engine probes it and falls back; the probe
-    is switched off here so that the four-chain code path runs whatever the process' queues look like): same bits as one chain."""
-    from pednstream_amd import NetworkEnvGenerator
-    from golden_util import DATA
-
-    def history(streams):
-        monkeypatch.setenv("PEDN_STREAMS", streams)
-        monkeypatch.setenv("PEDN_STREAM_PROBE", "0")
-        monkeypatch.setenv("PEDN_LINK_OWNER", owner if streams == "4" else "0")
-        np.random.seed(7)
-        net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=512, rng_seed=11)
-        e = net.engine()
-        assert e.plan_info()["chains"] == int(streams)
-        net.run(1, steps // 2)
-        net.network_loading(steps // 2)                      # a single step between two ranges
-        net.run(steps // 2 + 1, steps)
-        out = {f: e.read_block(LINK_FIELDS[f][0], 0, steps) for f in ALL_FIELDS}
-        out["tf"] = np.stack([np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 127, 128, 383, 384, 511)])
-        out["flags"] = e.error_flags()[1]
-        net.close()
-        return out
-
-    a, b = history("1"), history("4")
-    for f in a:
-        assert np.array_equal(a[f], b[f]), f
 
 
 @pytest.mark.parametrize("name,steps1,steps2,R,streams", [("nine_intersections", 260, 90, 64, "1"), ("long_corridor", 200, 70, 64, "1"),
@@ -669,8 +602,8 @@ def test_profile_run_uses_and_reports_the_launch_plan(monkeypatch):
     net.close()
 
 
-@pytest.mark.parametrize("fuse_tp,general,lds_limit,link_ns", [("1", "0", "64", "0"), ("0", "0", "64", "0"), ("1", "3", "1", "0"), ("1", "0", "64", "1")])
-def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, link_ns, monkeypatch):
+@pytest.mark.parametrize("fuse_tp,general,lds_limit", [("1", "0", "64"), ("0", "0", "64"), ("1", "3", "1")])
+def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, monkeypatch):
     """(with the next step's turn probabilities fused into the link update launch, and launched on their own: nine of the
     networks put separator links into softmax groups, whose density the fused launch re-derives)
     40 random scenarios (random trees + chords, all three fundamental diagrams, separators, controllers, activity,
@@ -684,7 +617,6 @@ def test_fuzz_random_networks_engine_equals_oracle(fuse_tp, general, lds_limit, 
     monkeypatch.setenv("PEDN_FUSE_TP", fuse_tp)
     monkeypatch.setenv("PEDN_TF_GENERAL", general)
     monkeypatch.setenv("PEDN_TF_LDS_LIMIT", lds_limit)
-    monkeypatch.setenv("PEDN_LINK_NS", link_ns)          # stand-alone link update: one replica per lane (default) / two
     ran = 0
     for seed in range(3000, 3040):
         adj, params, origins, dests = random_case(seed)
@@ -782,4 +714,49 @@ def test_od_weights_changed_between_steps_take_effect_at_the_next_step():
     tf = np.concatenate([e.get_turning_fractions(nd.index, 0) for nd in net.nodes.values()])
     assert np.array_equal(tf, o.tf())
     assert not np.array_equal(o.field("inflow")[:e.n_links, :90], g.state("inflow")[:, :90])      # the change mattered
+    net.close()
+
+
+@pytest.mark.parametrize("name", ["melbourne", "nine_intersections"])
+def test_zero_copy_pointer_held_across_steps_and_lazy_resets_needs_pedn_flush(name):
+    """a consumer that fetched pedn_device_ptr ONCE and orders itself behind pedn_stream() sees complete rows only after
+    pedn_flush (or a fresh pedn_device_ptr / pedn_synchronize): under the owner-wave / single-launch plans the last step's link update is
+    pending after pedn_run, and after pedn_reset_lazy the rows above the current step still hold the previous episode.  The stream-ordered
+    read through the held pointer must equal pedn_read after pedn_flush -- and the pointer must still be the same."""
+    torch = pytest.importorskip("torch")
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+    from pednstream_amd.rl_env import _DeviceBuffer
+
+    np.random.seed(7)
+    R = 64
+    net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=R, rng_seed=11)
+    e = net.engine()
+    assert e.plan_info()["link_update_by_next_node_kernel"]
+    T1 = e.T + 1
+    views = {}
+    for f in ("density", "num_pedestrians", "speed", "cumulative_inflow"):
+        fid = LINK_FIELDS[f][0]
+        ptr, cols, stride = e.device_ptr(fid)
+        views[f] = (fid, ptr, torch.as_tensor(_DeviceBuffer(ptr, (T1, cols, stride), "<f8" if fid < 7 else "<f4"), device="cuda"))
+    ext = torch.cuda.ExternalStream(e.stream_ptr())
+
+    def through_pointer(f, upto):
+        fid, ptr, view = views[f]
+        assert e.device_ptr(fid)[0] == ptr
+        torch.cuda.current_stream().wait_stream(ext)          # stream order only, no host synchronisation of the engine
+        return view[:upto, :e.n_links, :R].cpu().numpy()
+
+    net.run(1, 40, check=False)
+    e.flush()
+    for f in views:
+        assert np.array_equal(through_pointer(f, 40), e.read_block(views[f][0], 0, 40)[:, :e.n_links]), f
+    assert through_pointer("density", 40)[39].any() or name == "melbourne"          # the last step's link update is there
+    net.reset(lazy=True)
+    net.run(1, 12, check=False)
+    e.flush()
+    for f in views:
+        got = through_pointer(f, T1)
+        assert np.array_equal(got, e.read_block(views[f][0], 0, T1)[:, :e.n_links]), f
+        assert not got[13:].any(), f                           # the previous episode's rows are physically gone
     net.close()

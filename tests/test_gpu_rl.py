@@ -298,3 +298,108 @@ def test_recent_history_mode_serves_the_rl_step(case):
     obs, rew, *_ = env.step(acts[0:1])          # the rings start over with the episode
     assert np.array_equal(obs[0], ref_obs[0])
     env.close()
+
+
+def _feedback_policy(torch, B, n_actions):
+    """A policy whose actions depend on the observations it is handed (any missing dependency between the captured launches would
+    show) and on a state of its own that it advances in place (a linear congruential sequence per action slot: replayed or eager, the
+    same tensor ops in the same order)."""
+    state = (torch.arange(B * n_actions, device="cuda", dtype=torch.int64).reshape(B, n_actions) * 7919 + 17) % 2147483648
+
+    def policy(obs):
+        state.mul_(1103515245).add_(12345).remainder_(2147483648)
+        noise = state.double() / 2147483648.0
+        feedback = obs[:, :n_actions].double().abs() % 1.0
+        return (4.0 * (0.5 * noise + 0.5 * feedback)).contiguous()
+    return policy
+
+
+@pytest.mark.parametrize("scenario,history,gap,randomized", [("45_intersections", "full", 1, False), ("45_intersections", "recent", 2, False),
+                                                             ("45_intersections", "full", 1, True), ("nine_intersections", "full", 1, False)])
+def test_graph_replayed_rollout_equals_the_eager_one(scenario, history, gap, randomized):
+    """the env step with a device-resident step index (pedn_rl_clock_begin / pedn_rl_step_clocked) captured together
+    with the policy as ONE torch.cuda.CUDAGraph and replayed -- against the same rollout through step_device, step for step and bit for
+    bit: every observation, the accumulated rewards, histories, flags; two episodes with a lazy reset in between (the second one
+    shorter, so that rows of the first survive above it), an engine read in the middle of an episode (ends the clocked section, which the
+    rollout must notice and begin again), the last step of the horizon."""
+    torch = pytest.importorskip("torch")
+    g = Golden("rl_i45_opt3" if scenario == "45_intersections" else "rl_nine_opt3")
+    B = 128
+
+    def rollout(graphed):
+        np.random.seed(5)
+        env = VecPedNetEnv(scenario, n_envs=B, obs_mode="option3", action_gap=gap, reward_mode="all",
+                           network=build_network(g, n_replicas=B, rng_seed=3, history=history))
+        e = env.network.engine()
+        policy = _feedback_policy(torch, B, env.n_actions)
+        total = torch.zeros((B, len(env.possible_agents)), device="cuda", dtype=torch.float64)
+
+        def on_step(obs, rew):
+            total.add_(rew.double())
+
+        roll = env.capture(policy, on_step) if graphed else None
+        T = env.simulation_steps
+        out = []
+        for ep, n_steps in enumerate((T // gap, 60)):
+            env.reset(options={"randomize": True, "mode": "vectorised"} if randomized else None, seed=30 + ep)
+            total.zero_()
+            for k in range(n_steps):
+                if graphed:
+                    done = roll.step()
+                else:
+                    obs, rew, done = env.step_device(policy(env.device_views()[0]), sync=False)
+                    on_step(obs, rew)
+                if k % 37 == 5 or k == n_steps - 1:
+                    out.append(env.device_views()[0].clone())
+                if k == 90 and ep == 0:          # something else looks at the engine in mid-episode
+                    out.append(torch.as_tensor(e.read_block(2, env.sim_step - 2, env.sim_step)))
+                assert done == (k == T // gap - 1 and ep == 0)
+            torch.cuda.synchronize()
+            out.append(total.clone())
+            t_end = env.sim_step - 1
+            lo = max(0, t_end - 2)
+            out.extend(torch.as_tensor(e.read_block(f, lo if e.history_rows(f) < T + 1 else 0, t_end + 1)) for f in (0, 2, 3, 9, 10))
+            out.append(torch.as_tensor(e.error_flags()[1].astype(np.int64)))
+        if graphed:
+            assert roll.replays > 600 // gap and roll.eager_steps <= 3, (roll.replays, roll.eager_steps)
+            with pytest.raises(IndexError):
+                for _ in range(T):
+                    roll.step()
+        env.close()
+        return [x.cpu().numpy() for x in out]
+
+    a, b = rollout(False), rollout(True)
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), i
+
+
+def test_clocked_step_argument_errors_and_horizon_guard():
+    """pedn_rl_clock_begin refuses a step whose turning fractions are not prepared (the first step of an episode); a clocked step
+    enqueued beyond the horizon does nothing; pedn_rl_clock_end returns the next step."""
+    torch = pytest.importorskip("torch")
+    g = Golden("rl_nine_opt3")
+    B = 64
+    env = VecPedNetEnv("nine_intersections", n_envs=B, obs_mode="option3", network=build_network(g, n_replicas=B, rng_seed=3))
+    e = env.network.engine()
+    env.reset()
+    with pytest.raises(RuntimeError, match="not prepared"):
+        e.rl_clock_begin(1)
+    with pytest.raises(RuntimeError, match="pedn_rl_clock_begin"):
+        e.rl_step_clocked(0)
+    acts = torch.full((B, env.n_actions), 2.0, device="cuda", dtype=torch.float64)
+    env.step_device(acts)
+    T = env.simulation_steps
+    e.rl_clock_begin(2)
+    assert e.rl_clocked()
+    for _ in range(5):
+        e.rl_step_clocked(acts.data_ptr())
+    assert e.rl_clock_end() == 7 and not e.rl_clocked()
+    ref = e.read_block(2, 0, 7).copy()
+    e.rl_clock_begin(7)
+    for _ in range(T + 5):                        # runs into the horizon: the surplus launches are idle
+        e.rl_step_clocked(acts.data_ptr())
+    assert e.rl_clock_end() == T + 1
+    assert np.array_equal(e.read_block(2, 0, 7), ref) and e.error_flags()[0] == 0
+    assert e.read_block(2, T, T + 1).sum() > 0
+    env.close()

@@ -383,3 +383,27 @@ def test_device_randomiser_draws_the_distributions_of_the_host_generator():
     for a, b in zip(tfd, [np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 1, B - 1)]):
         assert np.array_equal(a, b)
     net.close()
+
+
+def test_unseeded_vectorised_resets_draw_fresh_scenarios():
+    """reset(options={'randomize': True, 'mode': 'vectorised'}) WITHOUT a seed (the usual Gym pattern seeds the first reset
+    only) must not draw the same scenario every episode: link parameters, OD weights and demand all differ between two such resets,
+    and the seed each one used is kept on the batch."""
+    from pednstream_amd.rl_env import VecPedNetEnv
+
+    B = 32
+    env = VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", data_dir=DATA, seed=9)
+    origin = next(n for n in env.network.nodes.values() if n.virtual_incoming_link is not None and n.node_id in env.network.origin_nodes)
+
+    def draw():
+        env.reset(options={"randomize": True, "mode": "vectorised"})
+        sc, e = env.scenarios, env.network.engine()
+        return sc.last_seed, sc.kc.copy(), sc.vf.copy(), sc.od_w.copy(), np.stack([e.get_demand(origin.index, r) for r in range(B)])
+
+    a, b = draw(), draw()
+    assert a[0] != b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert not np.array_equal(x, y)
+    env.reset(options={"randomize": True, "mode": "vectorised"}, seed=a[0])      # and the kept seed reproduces the draw
+    assert np.array_equal(env.scenarios.kc, a[1]) and np.array_equal(env.scenarios.od_w, a[3])
+    env.close()
