@@ -1040,7 +1040,13 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
 // CLK (the clocked env step, below): 6 -- the step index and valid_hi are values loaded from memory that stay live, and at 8 waves the
 // allocator answers with 20 vector spills; the batched RL step never fills the wave places of 8 anyway (544 workgroups at 2048 envs).
 template <bool PR, bool LP, int MD, bool TF, bool CLK = false>
-constexpr int node_kernel_waves() { return TF ? 2 : (LP || PR || MD > 6 || CLK) ? 6 : 8; }
+constexpr int node_kernel_waves() {
+#ifdef PEDN_PHASE_PROFILE
+  return TF ? 2 : 6;   // the profiling build's stamps need registers of their own
+#else
+  return TF ? 2 : (LP || PR || MD > 6 || CLK) ? 6 : 8;
+#endif
+}
 
 // The step index of a launch: the host's argument, or -- CLK, the device clock (pedn_rl_clock_begin / pedn_rl_step_clocked: an env step
 // whose launches have CONSTANT arguments, so that a captured graph can be replayed) -- read from v.clock:

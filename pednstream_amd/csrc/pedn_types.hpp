@@ -51,9 +51,7 @@ struct CorrRec {  // one lane group of link_kernel: both directions of a corrido
 // ---- route choice (path_finder.py:561-737), organised per row (= incoming slot) of a dynamic node: one wave of
 // turn_frac_kernel owns (row, 64 replicas).  Its static data are int32 word records fetched with vector loads (lane k holds
 // word k) and broadcast with v_readlane -- see turn_frac_body.
-#ifndef PEDN_TF_LDS_ROWS       // (overridable for the diagnostic builds of DESIGN 5.6 #63, #64)
 #define PEDN_TF_LDS_ROWS 64    // LDS rows (64 lanes x 8 bytes) of one workgroup = 4 rows of dynamic nodes, shared out by the host
-#endif
 #define PEDN_TROW_WORDS 128
 #define PEDN_TF_INL_ROWS 8     // LDS rows a slot wave of node_kernel<.., TF> has for the probabilities of its own row (single-launch plan)
 #define PEDN_TF_COOP_GROUPS 8   // rows with more multi-entry groups get a workgroup of their own (see turn_frac_body)

@@ -191,12 +191,17 @@ class VecPedNetEnv:
         self._device_views = None
 
     # ------------------------------------------------------------------------------------------------ API
-    def randomize(self, seed=None, mode="reference"):
+    AUTO_VECTORISED_FROM = 65      # randomize(mode="auto"): batches of this many envs and more draw their scenarios on the device
+
+    def randomize(self, seed=None, mode="auto"):
         """Draw a new scenario for every env and upload it per replica (``pednstream_amd.scenarios``).
 
         ``mode="reference"``: the reference's randomisers, one np.random stream consumed env after env
         (env_loader.py:183-259,363-424: link parameters of 20 % of the corridors, OD weights, demand pattern / lambdas) --
-        host-bound, ~0.25 ms per env.  ``mode="vectorised"``: the same distributions drawn for all envs at once ON THE DEVICE
+        bit-exact against the reference (goldens ``rand_*``) and host-bound, ~0.2 ms per env: 0.4 s for 2048 envs, twenty times an
+        episode's stepping time, which no prefetch thread can hide (it is ONE numpy stream, and the stepping loop holds the GIL).
+        ``mode="auto"`` (the default): "reference" up to 64 envs -- a drop-in single env or a small batch reproduces the reference's
+        numbers --, "vectorised" from 65 on.  ``mode="vectorised"``: the same distributions drawn for all envs at once ON THE DEVICE
         (``ScenarioBatch.draw_random`` -> ``pedn_randomize_scenarios``: nothing is uploaded); not the reference's random numbers.  Two deliberate differences from
         ``randomize_network`` in both modes: every env is perturbed from the BASE configuration (the reference keeps
         perturbing its already perturbed config), and ``generate_random_od_nodes`` is not applied because it changes the
@@ -206,6 +211,8 @@ class VecPedNetEnv:
         gen = self.env_generator
         if gen.config is None or gen.network_data is None:
             gen.network_data = gen.load_network_data(self.dataset)
+        if mode == "auto":
+            mode = "vectorised" if self.n_envs >= self.AUTO_VECTORISED_FROM else "reference"
         if mode == "vectorised" and self.scenarios is not None:
             batch = self.scenarios                 # nothing host-side to rebuild: the device draws in place (0.5 ms of Python per reset saved)
         else:
@@ -229,11 +236,12 @@ class VecPedNetEnv:
     def reset(self, options=None, seed=None):
         """All replicas back to t = 0: histories cleared, widths back to their initial values.  ``options={'randomize':
         True}`` additionally draws a new scenario per env (pz_pednet_env.py:143-193 rebuilds the network instead);
-        ``'mode': 'vectorised'`` selects the batched generator (see ``randomize``)."""
+        ``'mode'``: ``'reference'`` (the reference's np.random stream, env after env), ``'vectorised'`` (drawn on the device) or
+        ``'auto'`` (default: reference up to 64 envs, vectorised above -- see ``randomize``)."""
         net = self.network
         eng = net.engine()
         if options and options.get("randomize", False):
-            self.randomize(seed, mode=options.get("mode", "reference"))
+            self.randomize(seed, mode=options.get("mode", "auto"))
         net.reset(lazy=True)
         # every env starts from the same widths: broadcast on the device instead of four [L, R] uploads; the host mirrors (four [L, R]
         # arrays, 11 MB at 2048 envs) are not rebuilt -- they are marked stale and come back from the device if somebody looks

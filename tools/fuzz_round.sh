@@ -16,10 +16,7 @@ part_a() {
   PEDN_FUSE_TP=0 python3 -u tools/gpu_fuzz.py $((S+600*K)) $((S+900*K))
   PEDN_FUSE_TP=1 PEDN_TF_GENERAL=3 PEDN_TF_LDS_LIMIT=1 python3 -u tools/gpu_fuzz.py $((S+900*K)) $((S+1200*K))
   PEDN_FUSE_TP=1 python3 -u tools/gpu_fuzz.py $((S+1200*K)) $((S+1500*K)) scenarios
-  echo "# stand-alone link update with two replicas per lane in one / two segments (PEDN_LINK_NS=1|2; the default is one replica per lane),"
   echo "# every turning-fraction workgroup in front of the link update (PEDN_TF_HEAVY_GROUPS=0):"
-  PEDN_LINK_OWNER=0 PEDN_LINK_NS=1 python3 -u tools/gpu_fuzz.py $((S+2200*K)) $((S+2400*K))
-  PEDN_LINK_OWNER=0 PEDN_LINK_NS=2 python3 -u tools/gpu_fuzz.py $((S+2400*K)) $((S+2500*K))
   PEDN_TF_HEAVY_GROUPS=0 python3 -u tools/gpu_fuzz.py $((S+2500*K)) $((S+2700*K))
   echo "# node_kernel unrolled for 8 corridors (PEDN_NODE_MD=8):"
   PEDN_NODE_MD=8 python3 -u tools/gpu_fuzz.py $((S+2000*K)) $((S+2200*K))
@@ -27,10 +24,9 @@ part_a() {
   python3 -u tools/gpu_fuzz_chains.py $((S+3000*K)) $((S+3150*K))
 }
 part_b() {
-  echo "# owner-wave plan forced on for every model (PEDN_LINK_OWNER=1: node_kernel<LU>(t + 1) performs the link update of t), at 8 and 6 waves,"
+  echo "# owner-wave plan forced on for every model (PEDN_LINK_OWNER=1: node_kernel<LU>(t + 1) performs the link update of t),"
   echo "# with stand-alone turning fractions (every step flushes), per-replica scenarios, MD = 8; forced off; two chains == one chain:"
   PEDN_LINK_OWNER=1 python3 -u tools/gpu_fuzz.py $((S+3200*K)) $((S+3600*K))
-  PEDN_LINK_OWNER=1 PEDN_LU_WAVES=6 python3 -u tools/gpu_fuzz.py $((S+3600*K)) $((S+3800*K))
   PEDN_LINK_OWNER=1 PEDN_FUSE_TP=0 python3 -u tools/gpu_fuzz.py $((S+3800*K)) $((S+3900*K))
   PEDN_LINK_OWNER=1 python3 -u tools/gpu_fuzz.py $((S+3900*K)) $((S+4100*K)) scenarios
   PEDN_LINK_OWNER=1 PEDN_NODE_MD=8 python3 -u tools/gpu_fuzz.py $((S+4100*K)) $((S+4200*K))

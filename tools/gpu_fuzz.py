@@ -2,7 +2,7 @@
 (the generator of the offline reference campaign oracle/fuzz_vs_reference.py), 3 replicas each, every field and the turning
 fractions bit for bit, sticky error flags equal.
 
-    python tools/gpu_fuzz.py 4000 4300            # seeds; PEDN_FUSE_TP / PEDN_NODE_WAVES select the launch plan
+    python tools/gpu_fuzz.py 4000 4300            # seeds; PEDN_FUSE_TP / PEDN_LINK_OWNER / PEDN_INLINE_TF select the launch plan
     python tools/gpu_fuzz.py 4000 4300 scenarios  # additionally every replica gets its own k_critical / k_jam / free-flow speed,
                                                   # OD weights and demand (ScenarioBatch), the oracle the same per replica
 """
@@ -91,4 +91,4 @@ for seed in range(lo, hi):
         assert np.array_equal(tf, o.tf()), (seed, r)
         ran += 1
     net.close()
-print(f"{'per-replica scenarios, ' if per_replica else ''}fuse_tp={os.environ.get('PEDN_FUSE_TP','auto')} link_owner={os.environ.get('PEDN_LINK_OWNER','auto')} lu_waves={os.environ.get('PEDN_LU_WAVES','auto')} inline_tf={os.environ.get('PEDN_INLINE_TF','auto')} seeds {lo}..{hi}: {ran} replica runs bit-exact, {flagged} stopped at a reference raise site (same flag on both sides), {skipped} networks skipped (KeyError like the reference)")
+print(f"{'per-replica scenarios, ' if per_replica else ''}fuse_tp={os.environ.get('PEDN_FUSE_TP','auto')} link_owner={os.environ.get('PEDN_LINK_OWNER','auto')} inline_tf={os.environ.get('PEDN_INLINE_TF','auto')} seeds {lo}..{hi}: {ran} replica runs bit-exact, {flagged} stopped at a reference raise site (same flag on both sides), {skipped} networks skipped (KeyError like the reference)")

@@ -1,7 +1,7 @@
 """Per-launch durations (dispatch timestamps, pedn_profile_step) of a network x 1024 replicas under the bench's demand, for
 A/B runs inside ONE gpurun call: boxes differ by +-1 us per kernel, so builds and launch plans are compared on one box.
 
-    PEDN_LINK_NS=1 python tools/kernel_times.py melbourne delft
+    PEDN_FUSE_TP=0 python tools/kernel_times.py melbourne delft
     PEDN_HIP_LIB=$PWD/pednstream_amd/csrc/libpedn_hip_other.so python tools/kernel_times.py melbourne
 """
 import os
@@ -14,7 +14,7 @@ from bench import replica_demand  # noqa: E402
 from pednstream_amd import NetworkEnvGenerator  # noqa: E402
 
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
-tag = " ".join(f"{k}={os.environ[k]}" for k in ("PEDN_FUSE_TP", "PEDN_NODE_WAVES", "PEDN_LINK_NS", "PEDN_NODE_MD", "PEDN_STREAMS") if k in os.environ)
+tag = " ".join(f"{k}={os.environ[k]}" for k in ("PEDN_FUSE_TP", "PEDN_LINK_OWNER", "PEDN_INLINE_TF", "PEDN_NODE_MD", "PEDN_STREAMS") if k in os.environ)
 lib = os.path.basename(os.environ.get("PEDN_HIP_LIB", "libpedn_hip.so"))
 for network in sys.argv[1:]:
     R = 1024

@@ -17,7 +17,6 @@ LIB = os.path.join(ROOT, "pednstream_amd", "csrc", "libpedn_hip_phase.so")
 os.environ["PEDN_HIP_LIB"] = LIB
 # the ten 64-bit stamps live in registers: at node_kernel's normal budget (8 waves per SIMD, 64 VGPRs) the instrumented build spills
 # 25..32 vector registers and the picture is the spills'; at 6 waves (80 VGPRs) it spills none
-os.environ.setdefault("PEDN_NODE_WAVES", "6")
 
 from bench import replica_demand  # noqa: E402
 from pednstream_amd import NetworkEnvGenerator  # noqa: E402
@@ -49,7 +48,7 @@ def main():
         o = np.array(out[:], dtype=np.float64)
         n, total = o[10], o[11]
         print(f"== {network} x {R}: {int(n / 100)} active waves per launch, mean wave lifetime {total / n:.0f} s_memtime ticks "
-              f"(instrumented step at {os.environ['PEDN_NODE_WAVES']} waves per SIMD: {wall * 1e6:.1f} us)")
+              f"(instrumented step, built for 6 waves per SIMD: {wall * 1e6:.1f} us)")
         for i, name in enumerate(PHASES, start=1):
             print(f"   {name:48s} {o[i] / n:9.0f} ticks  {100 * o[i] / total:5.1f} %")
         net.close()

@@ -14,7 +14,7 @@ from bench import replica_demand  # noqa: E402
 from pednstream_amd import NetworkEnvGenerator  # noqa: E402
 
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
-KEYS = ("PEDN_LINK_OWNER", "PEDN_LU_WAVES", "PEDN_FUSE_TP", "PEDN_NODE_WAVES", "PEDN_LINK_NS", "PEDN_STREAMS")
+KEYS = ("PEDN_LINK_OWNER", "PEDN_INLINE_TF", "PEDN_FUSE_TP", "PEDN_STREAMS")
 tag = " ".join(f"{k[5:]}={os.environ[k]}" for k in KEYS if k in os.environ)
 lib = os.path.basename(os.environ.get("PEDN_HIP_LIB", "libpedn_hip.so"))
 for spec in sys.argv[1:]:
