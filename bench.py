@@ -365,8 +365,8 @@ def rl_end_to_end(network, B, steps=600):
     everything on the GPU, env-steps/s END TO END (host enqueue included) over `steps` iterations of one episode.  Two policies: a
     random one (one torch.rand per step) and a 3-layer MLP on the observations (float32, 64 hidden units).  Three ways of running the
     loop: step_device synchronising the host every step; streams chained by events (sync=False); and the whole iteration captured once
-    as a torch.cuda.CUDAGraph and replayed (VecPedNetEnv.capture: the engine's device-resident step clock makes the env step's launches
-    constant)."""
+    as a torch.cuda.CUDAGraph and replayed (VecPedNetEnv.capture, four policy steps per graph: the engine's device-resident step clock
+    makes the env step's launches constant).  What bounds the replayed loop: profiles/r05_graph_rollout.txt."""
     import torch
 
     from pednstream_amd.rl_env import VecPedNetEnv
@@ -400,16 +400,18 @@ def rl_end_to_end(network, B, steps=600):
             env.reset()
             ret.zero_()
             obs = env.device_views()[0]
-            roll = env.capture(policy, on_step, generators=[gen]) if label == "graph_replay" else None
+            roll = env.capture(policy, on_step, generators=[gen], steps_per_replay=4) if label == "graph_replay" else None
             for _ in range(8):                        # warm-up inside the episode (the graph is captured here)
                 if roll is not None:
-                    roll.step()
+                    if env.sim_step < 9:
+                        roll.step()
                 else:
                     o, r, _ = env.step_device(policy(obs), sync=label == "host_synchronised_every_step")
                     on_step(o, r)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(K - 8):
+            s0 = env.sim_step
+            while env.sim_step - s0 < K - 8:
                 if roll is not None:
                     roll.step()
                 else:
@@ -417,7 +419,8 @@ def rl_end_to_end(network, B, steps=600):
                     on_step(o, r)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            res[label] = {"value": B * (K - 8) / dt, "unit": "env-steps/s", "steps": K - 8, "us_per_iteration": dt / (K - 8) * 1e6,
+            n_it = env.sim_step - s0
+            res[label] = {"value": B * n_it / dt, "unit": "env-steps/s", "steps": n_it, "us_per_iteration": dt / n_it * 1e6,
                           "mean_return": float(ret.mean())}
             if roll is not None:
                 res[label]["replays"], res[label]["eager_steps"] = roll.replays, roll.eager_steps

@@ -328,13 +328,15 @@ class VecPedNetEnv:
             self._device_views = (view(1, self.n_obs), view(2, len(self.possible_agents)))
         return self._device_views
 
-    def capture(self, policy_fn, on_step=None, generators=()):
+    def capture(self, policy_fn, on_step=None, generators=(), steps_per_replay=1):
         """A graph-replayable rollout loop: ``policy_fn(obs) -> actions`` (torch ops only; obs is the engine's float32 observation buffer
         [n_envs, n_obs], actions a contiguous float64 CUDA tensor [n_envs, n_actions]) followed by one env step and ``on_step(obs, rewards)``
         (optional, torch ops only: reward bookkeeping, storing the transition) captured ONCE as a ``torch.cuda.CUDAGraph`` and replayed
         per policy step -- see ``GraphedRollout``.  ``generators``: every ``torch.Generator`` the two callables draw from other than the
-        default one (torch must know them before the capture: ``CUDAGraph.register_generator_state``)."""
-        return GraphedRollout(self, policy_fn, on_step, generators)
+        default one (torch must know them before the capture: ``CUDAGraph.register_generator_state``).  ``steps_per_replay`` > 1: that
+        many consecutive iterations in ONE graph (``GraphedRollout.step`` then advances by that many policy steps; the tail of an episode
+        that does not fill a graph is stepped eagerly)."""
+        return GraphedRollout(self, policy_fn, on_step, generators, steps_per_replay)
 
     def _ordered_behind_engine(self):
         """The caller's current torch stream waits (on the device) for everything enqueued on the engine's stream so far."""
@@ -379,10 +381,11 @@ class GraphedRollout:
     notices (``pedn_rl_clocked``) and begins a new clocked section.  The same numbers as ``step_device`` step for step
     (tests/test_gpu_rl.py)."""
 
-    def __init__(self, env, policy_fn, on_step=None, generators=()):
+    def __init__(self, env, policy_fn, on_step=None, generators=(), steps_per_replay=1):
         import torch
 
         self.env, self.policy_fn, self.on_step, self.generators = env, policy_fn, on_step, tuple(generators)
+        self.n = max(1, int(steps_per_replay))
         self.dev = torch.device("cuda", env.network.device)
         self.obs, self.rew = env.device_views()
         self.graph = None
@@ -400,17 +403,19 @@ class GraphedRollout:
         return a
 
     def step(self):
-        """One policy step for every env; returns True when the episode is over (``env.reset()`` next)."""
+        """One policy step for every env -- ``steps_per_replay`` of them when a whole graph fits what is left of the episode; returns
+        True when the episode is over (``env.reset()`` next)."""
         import torch
 
         env = self.env
         if env.sim_step + env.action_gap - 1 > env.simulation_steps:
             raise IndexError("episode is over; call reset()")
         eng = env.network._flush() if not env.network.engine().rl_clocked() else env.network.engine()
+        fits = env.sim_step + self.n * env.action_gap - 1 <= env.simulation_steps
         with torch.cuda.device(self.dev):
-            if not eng.rl_clocked():
+            if not eng.rl_clocked() or not fits:
                 begun = False
-                if env.sim_step > 1:
+                if env.sim_step > 1 and fits:
                     try:
                         eng.rl_clock_begin(env.sim_step)
                         begun = True
@@ -422,7 +427,7 @@ class GraphedRollout:
                     if self.on_step is not None:
                         self.on_step(self.obs, self.rew)
                     self.eager_steps += 1
-                    if not done:
+                    if not done and env.sim_step + self.n * env.action_gap - 1 <= env.simulation_steps:
                         eng.rl_clock_begin(env.sim_step)
                         env._ordered_behind_engine()
                     return done
@@ -431,7 +436,7 @@ class GraphedRollout:
                 self._capture()
             self.graph.replay()
         self.replays += 1
-        env.sim_step += env.action_gap
+        env.sim_step += self.n * env.action_gap
         env.network.current_step = env.sim_step - 1
         env.network._widths_stale = True
         return (env.sim_step - 1) >= env.simulation_steps
@@ -447,7 +452,7 @@ class GraphedRollout:
         for gen in self.generators:
             g.register_generator_state(gen)
         with torch.cuda.graph(g, stream=side):  # recorded, not run: the env does not advance
-            self._actions = self._iteration(torch.cuda.current_stream(self.dev).cuda_stream)
+            self._actions = [self._iteration(torch.cuda.current_stream(self.dev).cuda_stream) for _ in range(self.n)]
         self.graph = g
 
 

@@ -314,14 +314,15 @@ def _feedback_policy(torch, B, n_actions):
     return policy
 
 
-@pytest.mark.parametrize("scenario,history,gap,randomized", [("45_intersections", "full", 1, False), ("45_intersections", "recent", 2, False),
-                                                             ("45_intersections", "full", 1, True), ("nine_intersections", "full", 1, False)])
-def test_graph_replayed_rollout_equals_the_eager_one(scenario, history, gap, randomized):
+@pytest.mark.parametrize("scenario,history,gap,randomized,spr", [("45_intersections", "full", 1, False, 1), ("45_intersections", "recent", 2, False, 1),
+                                                                 ("45_intersections", "full", 1, True, 4), ("nine_intersections", "full", 1, False, 1),
+                                                                 ("nine_intersections", "recent", 1, False, 16)])
+def test_graph_replayed_rollout_equals_the_eager_one(scenario, history, gap, randomized, spr):
     """the env step with a device-resident step index (pedn_rl_clock_begin / pedn_rl_step_clocked) captured together
-    with the policy as ONE torch.cuda.CUDAGraph and replayed -- against the same rollout through step_device, step for step and bit for
-    bit: every observation, the accumulated rewards, histories, flags; two episodes with a lazy reset in between (the second one
-    shorter, so that rows of the first survive above it), an engine read in the middle of an episode (ends the clocked section, which the
-    rollout must notice and begin again), the last step of the horizon."""
+    with the policy as ONE torch.cuda.CUDAGraph (spr policy steps per graph) and replayed -- against the same rollout through
+    step_device, bit for bit: the observations at the end of each episode, the accumulated rewards, histories, flags; two episodes with a
+    lazy reset in between (the second one shorter, so that rows of the first survive above it), an engine read in the middle of an episode
+    (ends the clocked section, which the rollout must notice and begin again), the last step of the horizon."""
     torch = pytest.importorskip("torch")
     g = Golden("rl_i45_opt3" if scenario == "45_intersections" else "rl_nine_opt3")
     B = 128
@@ -337,31 +338,33 @@ def test_graph_replayed_rollout_equals_the_eager_one(scenario, history, gap, ran
         def on_step(obs, rew):
             total.add_(rew.double())
 
-        roll = env.capture(policy, on_step) if graphed else None
+        roll = env.capture(policy, on_step, steps_per_replay=spr) if graphed else None
         T = env.simulation_steps
         out = []
-        for ep, n_steps in enumerate((T // gap, 60)):
+        for ep, n_steps in enumerate((T // gap, 64)):
             env.reset(options={"randomize": True, "mode": "vectorised"} if randomized else None, seed=30 + ep)
             total.zero_()
-            for k in range(n_steps):
+            looked, done = False, False
+            while env.sim_step <= n_steps * gap:
+                assert not done
                 if graphed:
                     done = roll.step()
                 else:
                     obs, rew, done = env.step_device(policy(env.device_views()[0]), sync=False)
                     on_step(obs, rew)
-                if k % 37 == 5 or k == n_steps - 1:
-                    out.append(env.device_views()[0].clone())
-                if k == 90 and ep == 0:          # something else looks at the engine in mid-episode
-                    out.append(torch.as_tensor(e.read_block(2, env.sim_step - 2, env.sim_step)))
-                assert done == (k == T // gap - 1 and ep == 0)
+                if env.sim_step > 100 and ep == 0 and not looked:          # something else looks at the engine in mid-episode
+                    out.append(torch.as_tensor(e.read_block(2, 50, 52)))
+                    looked = True
+            assert done == (ep == 0)
             torch.cuda.synchronize()
+            out.append(env.device_views()[0].clone())
             out.append(total.clone())
             t_end = env.sim_step - 1
             lo = max(0, t_end - 2)
             out.extend(torch.as_tensor(e.read_block(f, lo if e.history_rows(f) < T + 1 else 0, t_end + 1)) for f in (0, 2, 3, 9, 10))
             out.append(torch.as_tensor(e.error_flags()[1].astype(np.int64)))
         if graphed:
-            assert roll.replays >= T // gap + 60 - 4 and roll.eager_steps <= 3, (roll.replays, roll.eager_steps)
+            assert roll.replays >= (T // gap + 64) // spr - 6 and roll.eager_steps <= 3 + 2 * spr, (roll.replays, roll.eager_steps)
             with pytest.raises(IndexError):
                 for _ in range(T):
                     roll.step()
