@@ -158,6 +158,12 @@ typedef struct pedn_model_desc {
    * reference hands the same programme to scipy/HiGHS; the optimum is degenerate, so the two agree in the objective value,
    * not necessarily in the vertex: parity for this mode is objective-level only (unpinned). */
   int32_t node_model;
+
+  /* [n_nodes] or NULL: measured cost of every node's slowest slot wave (any unit; ticks from kernel entry to the node kernel's first
+   * block barrier, tools/pack_calibrate.py -> <scenario>/pack_cost.json).  Nodes are binned into the node kernel's blocks of eight
+   * waves; a block lasts as long as its slowest wave, so nodes of similar cost should share a block.  Without it the bins are packed
+   * by a static estimate (the number of (turn, od) products of a node). */
+  const float* node_cost;
 } pedn_model_desc;
 
 typedef struct pedn_sim pedn_sim;
@@ -254,7 +260,8 @@ int pedn_set_streams(pedn_sim* sim, int32_t n);
  * (one launch per step), info[2] = streams created until one was found that overlaps with the engine's stream (0: not probed yet;
  * the runtime may map two streams onto one hardware queue, which would serialise the chains), info[3] = duration in microseconds of
  * the probe's two concurrent 300 us kernels on the pair kept (~300: they overlap, ~600: they do not); n = entries of info (>= 4);
- * with n >= 5: info[4] = 0 (reserved). */
+ * with n >= 5: info[4] = how nodes were packed into the node kernel's workgroups: 0 by degree, 1 by the static load estimate, 2 by
+ * the measured cost pedn_model_desc.node_cost. */
 int pedn_plan_info(pedn_sim* sim, int32_t* info, int32_t n);
 
 /* reset all histories and dynamic state to t = 0 (widths, turning fractions and demand are kept) */

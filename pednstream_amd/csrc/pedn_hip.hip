@@ -31,6 +31,7 @@ struct pedn_sim {
   int device = 0;
   int n_nodes = 0, n_turns = 0, n_demand = 0, n_od = 0, n_blocks = 0, n_ent = 0;
   int link_owner = 0;  // pedn_run: node_kernel(t + 1)'s slot waves perform the link update of t (one launch per step), PEDN_LINK_OWNER
+  int packed_by = 1;   // how nodes were binned into node_kernel's blocks: 0 by degree, 1 by the static load estimate, 2 by measured cost
   // Single-launch plan of small batches with dynamic turning fractions (inline_tf): every device-computed row is short enough for ONE
   // wave and its probabilities fit PEDN_TF_INL_ROWS LDS rows (inline_tf_ok), and the whole node_kernel grid is one generation at 4 waves
   // per SIMD: the slot waves of node_kernel<LU, TF> compute their own rows, a step is one launch.
@@ -91,6 +92,7 @@ struct pedn_sim {
   std::vector<double> h_ttab, h_ttab_r;         // host copies of turn_tab [T+1][n_turns] / turn_tab_r [n_turns][R] (tabulated rows: final values)
   std::vector<char> h_rl_link;
   LinkPR* d_prm = nullptr;           // per-replica link parameters [L][RS] (pedn_set_link_params, pedn_randomize_scenarios)
+  LinkPR* d_prm_draw = nullptr;      // recent-history mode: where pedn_randomize_scenarios draws before the result is accepted
   double *d_pair_pod_r = nullptr, *d_turn_tab_r = nullptr;
   // per-replica OD weights and the tables derived from them on the device (scenario_pod_tables)
   double *d_od_w_r = nullptr, *d_pod_tot = nullptr;     // [n_od][RS], [n_up][RS]
@@ -799,13 +801,22 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     // 31.6 us; PEDN_PACK_BY_LOAD=0 orders by slot count only).  Re-packing at run time by the cost the waves measure
     // themselves (ticks up to the first barrier, sampled every 100 / 250 steps) was tried and changed nothing (30.5 us either
     // way): the spread inside a block comes from step-to-step variation, not from which junctions share it.
-    std::vector<int> order(N), load(N, 0);
+    // Better than the estimate: the MEASURED cost of every node's slowest wave (pedn_model_desc.node_cost, from a calibration run of
+    // the profiling build, tools/pack_calibrate.py).  tools/pack_analysis.py: the wait at the first barrier is static (92 % of it is
+    // explained by the waves' mean arrival times); half of it is a node's waves waiting for each other -- inherent --, the other half is
+    // the packing's, and packing by measured cost removes at most half of that: 3.4-3.9 % of a wave's life.
+    // PEDN_PACK_BY_LOAD=0: by degree only, =1: by the static estimate even when a measured cost is given.
+    std::vector<int> order(N);
+    std::vector<double> load(N, 0.0);
     for (int n = 0; n < N; ++n) order[n] = n;
     auto deg = [&](int n) { return m->node_slot_ptr[n + 1] - m->node_slot_ptr[n]; };
-    bool by_load = true;
-    if (const char* f = getenv("PEDN_PACK_BY_LOAD")) by_load = atoi(f) != 0;
-    if (by_load)
+    int by_load = m->node_cost ? 2 : 1;
+    if (const char* f = getenv("PEDN_PACK_BY_LOAD")) by_load = std::min(atoi(f), by_load);
+    if (by_load == 2)
+      for (int n = 0; n < N; ++n) load[n] = (double)m->node_cost[n];
+    else if (by_load == 1)
       for (int n = 0; n < N; ++n) load[n] = m->turn_pair_ptr[m->node_turn_ptr[n + 1]] - m->turn_pair_ptr[m->node_turn_ptr[n]];
+    s->packed_by = by_load;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] != load[b] ? load[a] > load[b] : deg(a) > deg(b); });
     std::vector<std::vector<int>> bins;
     std::vector<int> fill;
@@ -1601,7 +1612,7 @@ int pedn_plan_info(pedn_sim* s, int32_t* info, int32_t n) {
   info[1] = s->link_owner && !s->node_lp && s->v.n_pairs_corr > 0;   // (with device-computed rows: the single-launch plan, inline_tf)
   info[2] = s->stream_probe_attempts;
   info[3] = (int32_t)(s->stream_probe_ms * 1000.0f + 0.5f);
-  if (n >= 5) info[4] = 0;   // (reserved: the persistent plan of round 4 was removed)
+  if (n >= 5) info[4] = s->packed_by;   // bins of node_kernel packed by 0 degree, 1 the static load estimate, 2 measured node cost
   return PEDN_OK;
 }
 
@@ -1949,16 +1960,25 @@ int pedn_randomize_scenarios(pedn_sim* s, uint64_t seed, double link_fraction, i
     if ((rc = ensure_link_records(s)) != PEDN_OK) return rc;
     if (!s->d_max_tau && (rc = dalloc(s, 1, &s->d_max_tau)) != PEDN_OK) return rc;
     HIP_TRY(s, hipMemsetAsync(s->d_max_tau, 0, sizeof(int), s->stream));
-    hipLaunchKernelGGL(rand_links_kernel, dim3((unsigned)((v.RS + 63) / 64)), dim3(64), 0, s->stream, v, s->d_prm, k, k0, k1, s->d_max_tau);
+    // recent-history mode: the cumulative_outflow ring must cover the longest shock-wave look-back drawn -- checked BEFORE the draw
+    // replaces the scenario in use: the records are drawn into a second buffer and the two are swapped only when the check has passed
+    LinkPR* dst = s->d_prm;
+    if (v.hist) {
+      if (!s->d_prm_draw && (rc = dalloc(s, (size_t)v.L * v.RS, &s->d_prm_draw)) != PEDN_OK) return rc;
+      dst = s->d_prm_draw;
+    }
+    hipLaunchKernelGGL(rand_links_kernel, dim3((unsigned)((v.RS + 63) / 64)), dim3(64), 0, s->stream, v, dst, k, k0, k1, s->d_max_tau);
     HIP_TRY(s, hipGetLastError());
-    v.prm = s->d_prm;
-    v.pr = 1;
-    if (v.hist) {  // recent-history mode: the cumulative_outflow ring must cover the longest shock-wave look-back drawn
+    if (v.hist) {
       int mt = 0;
       HIP_TRY(s, hipMemcpyAsync(&mt, s->d_max_tau, sizeof(int), hipMemcpyDeviceToHost, s->stream));
       HIP_TRY(s, hipStreamSynchronize(s->stream));
-      if (mt + 2 > s->rows64[F_CO]) return fail(s, PEDN_E_ARG, "a drawn shock-wave look-back (" + std::to_string(mt) + ") is longer than the cumulative_outflow ring (recent-history mode)");
+      if (mt + 2 > s->rows64[F_CO])   // the engine keeps the scenario it had
+        return fail(s, PEDN_E_ARG, "a drawn shock-wave look-back (" + std::to_string(mt) + ") is longer than the cumulative_outflow ring (recent-history mode)");
+      std::swap(s->d_prm, s->d_prm_draw);
     }
+    v.prm = s->d_prm;
+    v.pr = 1;
   }
   if ((what & 2) && s->n_pair > 0) {
     if ((rc = ensure_pod_tables(s)) != PEDN_OK) return rc;
@@ -2319,6 +2339,13 @@ extern "C" int pedn_debug_lt_timeline(unsigned long long* out, int n_blocks, int
   if (zero) return (int)hipMemset(dev, 0, sizeof(unsigned long long) * PEDN_LT_BLOCKS * 4);
   if (n_blocks > PEDN_LT_BLOCKS) n_blocks = PEDN_LT_BLOCKS;
   return (int)hipMemcpy(out, dev, sizeof(unsigned long long) * (size_t)n_blocks * 4, hipMemcpyDeviceToHost);
+}
+// raw accumulators of the first n_waves waves of the grid: [wave][12] = 9 phase sums, -, count, lifetime (tools/pack_analysis.py)
+extern "C" int pedn_debug_phase_waves(unsigned long long* out, int n_waves) {
+  void* dev = nullptr;
+  if (hipGetSymbolAddress(&dev, HIP_SYMBOL(g_phase)) != hipSuccess) return -1;
+  if (n_waves > PEDN_PHASE_WAVES) n_waves = PEDN_PHASE_WAVES;
+  return (int)hipMemcpy(out, dev, sizeof(unsigned long long) * (size_t)n_waves * 12, hipMemcpyDeviceToHost);
 }
 extern "C" int pedn_debug_phases(unsigned long long* out, int zero) {
   const size_t n = (size_t)PEDN_PHASE_WAVES * 12;

@@ -764,7 +764,12 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
       const int tw0 = rw[lane], tw1 = rw[64 + lane];
       turn_frac_body<PR, true, HIST, true>(v, t, 0u, pedn_lds + v.tf_lds_off + wave * PEDN_TF_INL_LDS, W.trow, r0, tw0, tw1);
     }
-    __syncthreads();   // the meeting with the slot waves (below); the helpers are done
+    __syncthreads();   // the meeting with the slot waves (below); the helpers' work is done
+    // ... but they stay for the workgroup's two other barriers, so that EVERY wave of the workgroup passes the same three (a barrier
+    // that some waves skip by retiring works on this hardware -- s_barrier counts the waves that are still alive -- and is outside
+    // the HIP barrier model)
+    __syncthreads();
+    __syncthreads();
     return;
   }
 

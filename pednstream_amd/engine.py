@@ -46,6 +46,7 @@ class ModelDesc(C.Structure):
         ("grp_ent_ptr", _I32P), ("grp_allphys", _I32P), ("grp_node", _I32P), ("ent_link", _I32P), ("ent_dist", _F64P),
         ("turn_pair_ptr", _I32P), ("pair_ent", _I32P), ("pair_upod", _I32P),
         ("history_mode", C.c_int32), ("node_model", C.c_int32),
+        ("node_cost", _F32P),
     ]
 
 
@@ -67,6 +68,8 @@ def build_model_desc(model: dict):
     for name, ctype in ModelDesc._fields_:
         if name == "abi_version":
             desc.abi_version = ABI_VERSION
+        elif name == "node_cost" and model.get("node_cost") is None:
+            desc.node_cost = None                                 # optional: no measured packing cost for this scenario
         elif ctype in _PTR_TYPES:
             arr = np.ascontiguousarray(model[name], dtype=_PTR_TYPES[ctype])
             if arr.size == 0:
@@ -442,7 +445,7 @@ class Engine:
         info = np.zeros(5, dtype=np.int32)
         self._ck(self._lib.pedn_plan_info(self._h, info.ctypes.data_as(_I32P), 5))
         return {"chains": int(info[0]), "link_update_by_next_node_kernel": bool(info[1]), "stream_probe_attempts": int(info[2]),
-                "stream_probe_us": int(info[3])}
+                "stream_probe_us": int(info[3]), "packed_by": ("degree", "static_load_estimate", "measured_node_cost")[int(info[4])]}
 
     def set_streams(self, n):
         """Launch plan of run() for long ranges: 1 chain of launches, or 2 (the halves of the replica batch on two streams; falls

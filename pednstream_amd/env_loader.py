@@ -111,6 +111,12 @@ class NetworkEnvGenerator:
             destination_nodes=self.config.get("destination_nodes", []),
             demand_pattern=custom_demand_functions, od_flows=self.config.get("od_flows", None),
             pos=self.network_data.get("node_positions"), **network_kwargs)
+        # optional tuning artefact of this repository (not a reference file): the measured cost of every node's slowest node-kernel wave,
+        # by which the engine packs nodes into workgroups (tools/pack_calibrate.py; include/pedn.h: pedn_model_desc.node_cost)
+        cost_path = os.path.join(self.data_dir, f"{yaml_file_path}", "pack_cost.json")
+        if os.path.exists(cost_path):
+            with open(cost_path) as f:
+                self.network.node_pack_cost = {int(k): float(v) for k, v in json.load(f)["node_cost"].items()}
         return self.network
 
     # ---------------------------------------------------------------------------------------------- randomisers

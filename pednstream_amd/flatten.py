@@ -50,6 +50,9 @@ def flatten_network(net) -> dict:
         else:
             dem_row.append(-1)
     m["node_id"] = np.array([nd.node_id for nd in nodes], dtype=I32)
+    # measured packing cost per node (tools/pack_calibrate.py), when the scenario directory carries one for every node
+    cost = getattr(net, "node_pack_cost", None)
+    m["node_cost"] = (np.array([cost[nd.node_id] for nd in nodes], dtype=F32) if cost and all(nd.node_id in cost for nd in nodes) else None)
     m["node_kind"] = np.array(kind, dtype=I32)
     m["node_slot_ptr"] = np.array(slot_ptr, dtype=I32)
     m["node_turn_ptr"] = np.array(turn_ptr, dtype=I32)

@@ -132,6 +132,31 @@ def test_bench_under_the_launcher_runs_the_rccl_branch_once():
     assert strong["scaling"] == "strong" and strong["config"]["replicas_per_gpu"] == 512 and strong["config"]["replicas_total"] == 512
 
 
+def test_bench_two_ranks_rehearsal_prints_one_compact_line():
+    """`python bench.py --gpus 2 --share-device`: the N > 1 path of bench.py with two REAL ranks (gloo rendezvous, both on GPU 0 -- RCCL
+    refuses to share a device): rank 0 alone prints the line, in the same compact shape as N = 1, with both ranks counted and the
+    whole-job value = both ranks' replicas; strong scaling splits the total."""
+    import json
+    import subprocess
+
+    pytest.importorskip("torch")
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    for extra, per_gpu, scaling in ((["--replicas", "256"], 256, "weak"), (["--total-replicas", "512"], 256, "strong")):
+        out = subprocess.run([sys.executable, bench, "--gpus", "2", "--share-device", "--steps", "40", "--warmup", "10", "--no-cpu-baseline"] + extra,
+                             capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) < 4096, out.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == scaling
+        assert d["config"]["replicas_per_gpu"] == per_gpu and d["config"]["replicas_total"] == 2 * per_gpu
+        assert abs(d["value"] - 938 * 2 * per_gpu * 40 / (d["ms_per_step"] * 40e-3)) < 1e-3 * d["value"]
+        assert d["roofline"]["frac"] > 0 and "cpu_baseline" not in d and "extra" not in d
+
+
 def test_bench_rl_lines_plain_and_randomized():
     """The config #5 measurement that rides in the driver's bench line (bench.py: measure_rl), at a small size: both variants
     produce a complete line, the randomised one really ran with per-env scenarios."""

@@ -760,3 +760,34 @@ def test_zero_copy_pointer_held_across_steps_and_lazy_resets_needs_pedn_flush(na
         assert np.array_equal(got, e.read_block(views[f][0], 0, T1)[:, :e.n_links]), f
         assert not got[13:].any(), f                           # the previous episode's rows are physically gone
     net.close()
+
+
+def test_bin_packing_by_degree_static_estimate_and_measured_cost_gives_identical_histories(monkeypatch):
+    """Which nodes share a node-kernel workgroup (PEDN_PACK_BY_LOAD: 0 by degree, 1 by the static load estimate, 2 by the measured node
+    cost of data/melbourne/pack_cost.json -- the default when the scenario carries one) only decides how long a workgroup waits at its
+    barriers: every field, flag and fraction is the same."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    def history(pack):
+        monkeypatch.delenv("PEDN_PACK_BY_LOAD", raising=False) if pack is None else monkeypatch.setenv("PEDN_PACK_BY_LOAD", pack)
+        np.random.seed(7)
+        net = NetworkEnvGenerator(DATA).create_network("melbourne", verbose=False, n_replicas=64, rng_seed=11)
+        for nid in net.origin_nodes:
+            net.set_demand_matrix(nid, np.stack([np.random.default_rng(5 + r).poisson(60.0, net.simulation_steps).astype(np.float64) for r in range(64)]))
+        net.run(1, 80)
+        e = net.engine()
+        out = {f: e.read_block(LINK_FIELDS[f][0], 0, 80) for f in ALL_FIELDS}
+        out["flags"] = e.error_flags()[1]
+        packed = e.plan_info()["packed_by"]
+        net.close()
+        return out, packed
+
+    ref, how = history(None)
+    assert how == "measured_node_cost"
+    for pack, name in (("0", "degree"), ("1", "static_load_estimate")):
+        got, how = history(pack)
+        assert how == name
+        for f in ref:
+            assert np.array_equal(ref[f], got[f]), (pack, f)
+    assert ref["cumulative_inflow"][79].sum() > 0

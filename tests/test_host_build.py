@@ -138,3 +138,25 @@ def test_array_statics_equal_the_scalar_expressions():
         for i in range(L):
             for j in range(R):
                 assert derive_statics(float(length[i, 0]), vf[i, j], kc[i, j], kj[i, j], unit_time) == (tt0[i, j], fft[i, j], tsw[i, j])
+
+
+def test_measured_packing_cost_travels_from_the_scenario_directory_to_the_model_description():
+    """data/<scenario>/pack_cost.json (tools/pack_calibrate.py) -> Network.node_pack_cost -> flatten_network()['node_cost'] in node
+    order -> pedn_model_desc.node_cost; a scenario without the file hands over NULL (the static estimate packs the bins)."""
+    from golden_util import DATA
+    from pednstream_amd import NetworkEnvGenerator
+    from pednstream_amd.engine import build_model_desc
+
+    np.random.seed(0)
+    net = NetworkEnvGenerator(DATA).create_network("melbourne", verbose=False)
+    with open(f"{DATA}/melbourne/pack_cost.json") as f:
+        ref = {int(k): v for k, v in json.load(f)["node_cost"].items()}
+    m = flatten_network(net)
+    assert m["node_cost"].dtype == np.float32 and len(m["node_cost"]) == m["n_nodes"] == len(ref)
+    assert all(np.float32(ref[int(nid)]) == c for nid, c in zip(m["node_id"], m["node_cost"])) and m["node_cost"].min() > 0
+    desc, keep = build_model_desc(m)
+    assert bool(desc.node_cost) and desc.node_cost[0] == m["node_cost"][0]
+    np.random.seed(0)
+    six = NetworkEnvGenerator(DATA).create_network("od_flow_example", verbose=False)
+    m6 = flatten_network(six)
+    assert m6["node_cost"] is None and not bool(build_model_desc(m6)[0].node_cost)

@@ -14,7 +14,7 @@ from bench import replica_demand  # noqa: E402
 from pednstream_amd import NetworkEnvGenerator  # noqa: E402
 
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
-KEYS = ("PEDN_LINK_OWNER", "PEDN_INLINE_TF", "PEDN_FUSE_TP", "PEDN_STREAMS")
+KEYS = ("PEDN_LINK_OWNER", "PEDN_INLINE_TF", "PEDN_FUSE_TP", "PEDN_STREAMS", "PEDN_PACK_BY_LOAD")
 tag = " ".join(f"{k[5:]}={os.environ[k]}" for k in KEYS if k in os.environ)
 lib = os.path.basename(os.environ.get("PEDN_HIP_LIB", "libpedn_hip.so"))
 for spec in sys.argv[1:]:
@@ -41,5 +41,5 @@ for spec in sys.argv[1:]:
     (tf, node, link), chains = e.profile_run(101 + n, 101 + n + 40)
     rc, _ = e.error_flags()
     print(f"{network:10s} x{R:5d} {lib:22s} {tag or 'default plan':28s} {best:6.2f} us/step   chains {chains}  node_kernel {node * 1e3:6.2f}  "
-          f"second launch {link * 1e3:6.2f}  stand-alone tf {tf * 1e3:5.2f}  flags {rc}  probe {plan['stream_probe_attempts']}x {plan['stream_probe_us']} us", flush=True)
+          f"second launch {link * 1e3:6.2f}  stand-alone tf {tf * 1e3:5.2f}  flags {rc}  packed by {plan['packed_by']}  probe {plan['stream_probe_attempts']}x {plan['stream_probe_us']} us", flush=True)
     net.close()
