@@ -358,6 +358,10 @@ int pedn_rl_clock_end(pedn_sim* sim, int32_t* t);
 /* 1 while a clocked section is open (pedn_rl_clock_begin .. the next call that ends it), else 0: a caller that replays a captured
  * graph checks this before every replay -- another entry point may have ended the section -- and begins it again if need be */
 int pedn_rl_clocked(pedn_sim* sim);
+/* A hash of everything the launches of pedn_rl_step_clocked carry by value (device pointers, sizes, whether replicas have their own
+ * scenarios, the agent set) and of what selects their kernels and grids.  A captured graph is valid as long as this value is the one
+ * it was captured under: e.g. the first reset(options={'randomize': True}) switches the step to the per-replica-parameter kernels. */
+uint64_t pedn_rl_clock_signature(pedn_sim* sim);
 /* device buffers for zero-copy consumers: 0 actions (f64 [R][n_actions]), 1 observations (f32 [R][n_obs]), 2 rewards (f32 [R][n_agents]) */
 void* pedn_rl_device_ptr(pedn_sim* sim, int32_t which);
 

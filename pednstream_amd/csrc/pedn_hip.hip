@@ -2286,6 +2286,29 @@ int pedn_rl_step_clocked(pedn_sim* s, const double* actions, int32_t action_gap,
 
 int pedn_rl_clocked(pedn_sim* s) { return s && s->clocked ? 1 : 0; }
 
+// What the launches of pedn_rl_step_clocked are made of: the device view they carry BY VALUE (pointers, sizes, per-replica-scenario
+// switches -- not valid_hi, which a clocked launch takes from the clock), the RL view, and what selects kernels and grids.
+uint64_t pedn_rl_clock_signature(pedn_sim* s) {
+  if (!s) return 0;
+  DevView v = s->v;
+  v.valid_hi = 0;
+  v.rl_actions = nullptr;
+  uint64_t h = 1469598103934665603ull;   // FNV-1a
+  auto mix = [&](const void* p, size_t n) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+  };
+  static_assert(std::is_trivially_copyable<DevView>::value && std::is_trivially_copyable<RlView>::value, "hashed as bytes");
+  DevView z;
+  memset(&z, 0, sizeof z);       // (padding bytes of the copy are whatever the copy left there: hash field images laid over zeros)
+  memcpy(&z, &v, sizeof v);
+  mix(&z, sizeof z);
+  mix(&s->rl, sizeof s->rl);
+  const int64_t sel[8] = {s->rl_fold, s->n_tf_heavy_quads, s->n_blocks, (int64_t)s->node_lds, s->max_degree, s->node_lp, s->fuse_tp, s->fuse_obs};
+  mix(sel, sizeof sel);
+  return h;
+}
+
 int pedn_rl_clock_end(pedn_sim* s, int32_t* t) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   HIP_TRY(s, hipSetDevice(s->device));

@@ -173,6 +173,7 @@ def _load():
         "pedn_rl_step_clocked": (C.c_int, [P, C.c_void_p, C.c_int32, C.c_void_p]),
         "pedn_rl_clock_end": (C.c_int, [P, C.POINTER(C.c_int32)]),
         "pedn_rl_clocked": (C.c_int, [P]),
+        "pedn_rl_clock_signature": (C.c_uint64, [P]),
         "pedn_flush": (C.c_int, [P]),
         "pedn_device_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _F64P, _F64P, C.c_uint64, _F64P]),
     }
@@ -203,7 +204,7 @@ EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy",
            "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_reset_lazy", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_plan_info", "pedn_rl_configure",
            "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
            "pedn_set_od_weights_per_replica", "pedn_get_od_weights_per_replica", "pedn_get_link_params", "pedn_randomize_scenarios", "pedn_reset_widths",
-           "pedn_flush", "pedn_rl_clock_begin", "pedn_rl_step_clocked", "pedn_rl_clock_end", "pedn_rl_clocked"]
+           "pedn_flush", "pedn_rl_clock_begin", "pedn_rl_step_clocked", "pedn_rl_clock_end", "pedn_rl_clocked", "pedn_rl_clock_signature"]
 
 
 def _p(a, dtype=np.float64):
@@ -516,6 +517,10 @@ class Engine:
 
     def rl_clocked(self):
         return bool(self._lib.pedn_rl_clocked(self._h))
+
+    def rl_clock_signature(self):
+        """Hash of what the clocked step's launches carry by value: a captured graph is valid while it does not change."""
+        return int(self._lib.pedn_rl_clock_signature(self._h))
 
     def rl_clock_end(self):
         """Ends the clocked section (synchronises the device); returns the next step to run."""

@@ -390,7 +390,8 @@ class GraphedRollout:
         self.obs, self.rew = env.device_views()
         self.graph = None
         self._actions = None           # the policy's output tensor of the captured iteration (its address is what the graph reads)
-        self.replays = self.eager_steps = 0
+        self.replays = self.eager_steps = self.recaptures = 0
+        self._signature, self._verify = None, True
 
     def _iteration(self, stream_ptr):
         a = self.policy_fn(self.obs)
@@ -414,6 +415,7 @@ class GraphedRollout:
         fits = env.sim_step + self.n * env.action_gap - 1 <= env.simulation_steps
         with torch.cuda.device(self.dev):
             if not eng.rl_clocked() or not fits:
+                self._verify = True
                 begun = False
                 if env.sim_step > 1 and fits:
                     try:
@@ -432,6 +434,14 @@ class GraphedRollout:
                         env._ordered_behind_engine()
                     return done
                 env._ordered_behind_engine()
+            if self._verify:
+                # the captured launches carry the engine's device view by value: a scenario switch since the capture (the first
+                # randomised reset brings the per-replica-parameter kernels) makes the graph stale -- captured again.  Only something
+                # that ended the clocked section can have changed it, so the check runs once per section.
+                self._verify = False
+                if self.graph is not None and eng.rl_clock_signature() != self._signature:
+                    self.graph = None
+                    self.recaptures += 1
             if self.graph is None:
                 self._capture()
             self.graph.replay()
@@ -454,6 +464,7 @@ class GraphedRollout:
         with torch.cuda.graph(g, stream=side):  # recorded, not run: the env does not advance
             self._actions = [self._iteration(torch.cuda.current_stream(self.dev).cuda_stream) for _ in range(self.n)]
         self.graph = g
+        self._signature = self.env.network.engine().rl_clock_signature()
 
 
 class PedNetParallelEnv:

@@ -377,6 +377,39 @@ def test_graph_replayed_rollout_equals_the_eager_one(scenario, history, gap, ran
         assert np.array_equal(x, y), i
 
 
+def test_graph_is_captured_again_when_a_randomised_reset_switches_the_kernels():
+    """The captured launches carry the engine's device view by value.  A rollout captured during a plain episode must not be replayed
+    after reset(options={'randomize': True}) gave every env its own parameters (other kernels, other pointers): the rollout sees the
+    launch signature change, captures again, and the episode equals the eager one."""
+    torch = pytest.importorskip("torch")
+    g = Golden("rl_i45_opt3")
+    B, steps = 128, 40
+
+    def run(graphed):
+        np.random.seed(5)
+        env = VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", network=build_network(g, n_replicas=B, rng_seed=3))
+        policy = _feedback_policy(torch, B, env.n_actions)
+        roll = env.capture(policy) if graphed else None
+        out = []
+        for ep, options in enumerate((None, {"randomize": True, "mode": "vectorised"}, None)):
+            env.reset(options=options, seed=7)
+            for _ in range(steps):
+                if graphed:
+                    roll.step()
+                else:
+                    env.step_device(policy(env.device_views()[0]), sync=False)
+            torch.cuda.synchronize()
+            out.append(env.device_views()[0].clone().cpu().numpy())
+            out.append(env.network.engine().read_block(2, 0, steps))
+        if graphed:
+            assert roll.recaptures == 1, roll.recaptures          # plain -> per-replica scenarios; the third episode keeps them
+        env.close()
+        return out
+
+    for x, y in zip(run(False), run(True)):
+        assert np.array_equal(x, y)
+
+
 def test_clocked_step_argument_errors_and_horizon_guard():
     """pedn_rl_clock_begin refuses a step whose turning fractions are not prepared (the first step of an episode); a clocked step
     enqueued beyond the horizon does nothing; pedn_rl_clock_end returns the next step."""

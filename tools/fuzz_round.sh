@@ -47,6 +47,9 @@ part_b() {
   echo "# tools/gpu_fuzz_rl.py: observations and rewards of the batched RL step against the restated RL glue:"
   python3 -u tools/gpu_fuzz_rl.py $S $((S+400*K))
   PEDN_RL_FOLD=0 python3 -u tools/gpu_fuzz_rl.py $((S+400*K)) $((S+600*K))
+  echo "# ... with every step but the first through the device-resident step clock (the launches a captured graph replays):"
+  python3 -u tools/gpu_fuzz_rl.py $((S+600*K)) $((S+1000*K)) clocked
+  PEDN_RL_FOLD=0 python3 -u tools/gpu_fuzz_rl.py $((S+1000*K)) $((S+1200*K)) clocked
 }
 # line-buffered: a block-buffered grep held everything back until the script ended, the run looked silent for more than 7 minutes and
 # was killed (gpurun_out/fuzz_d_call.log of round 3); the campaigns also print a heartbeat line every 100-200 seeds

@@ -4,6 +4,8 @@ observations and rewards of VecPedNetEnv must equal tests/rl_oracle.py (the refe
 itself pinned by the rl_* goldens) bit for bit.
 
     python tools/gpu_fuzz_rl.py 4000 4400          # seeds; PEDN_FUSE_OBS=0 keeps the observations in their own launch
+    python tools/gpu_fuzz_rl.py 4000 4400 clocked  # every step but the first through the device-resident step clock
+                                                   # (pedn_rl_clock_begin / pedn_rl_step_clocked: the launches a captured graph replays)
 """
 import copy
 import os
@@ -22,6 +24,9 @@ from rl_oracle import RlOracle  # noqa: E402
 from test_rl_golden import agent_spec  # noqa: E402
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+clocked = len(sys.argv) > 3 and sys.argv[3] == "clocked"
+if clocked:
+    import torch
 B, steps = 4, 30
 ran = no_agents = skipped = 0
 for seed in range(lo, hi):
@@ -52,14 +57,27 @@ for seed in range(lo, hi):
     checks = {r: RlOracle(net, model, spec, mode, normalize, gap, seed=seed, replica=r, reward_mode="all") for r in (0, B - 1)}
     n = min(steps, (net.simulation_steps - 1) // gap)
     hi_w = float(max(l.width for l in net.links.values())) + 0.5
+    eng = net.engine()
     for k in range(n):
         acts = rng.uniform(-0.5, hi_w, size=(B, env.n_actions)).astype(np.float32)
-        obs, rew, *_ = env.step(acts)
+        if clocked and k > 0:
+            if not eng.rl_clocked():
+                eng.rl_clock_begin(env.sim_step)
+            a = torch.as_tensor(acts.astype(np.float64), device="cuda")
+            torch.cuda.synchronize()
+            eng.rl_step_clocked(a.data_ptr(), gap)
+            torch.cuda.synchronize()
+            env.sim_step += gap
+            obs, rew = (x.cpu().numpy() for x in env.device_views())
+            if k % 11 == 10:                  # now and then something else touches the engine: the clocked section ends and begins again
+                assert eng.rl_clock_end() == env.sim_step
+        else:
+            obs, rew, *_ = env.step(acts)
         for r, orc in checks.items():
             o, w = orc.step(acts[r])
             assert np.array_equal(obs[r], o), (seed, k, r, mode, normalize, gap)
             assert np.array_equal(rew[r], w), (seed, k, r, mode, normalize, gap)
     ran += 1
     env.close()
-print(f"fuse_obs={os.environ.get('PEDN_FUSE_OBS', 'auto')} seeds {lo}..{hi}: {ran} controlled scenarios x 2 checked replicas bit-exact on observations and "
+print(f"{'clocked steps, ' if clocked else ''}fuse_obs={os.environ.get('PEDN_FUSE_OBS', 'auto')} seeds {lo}..{hi}: {ran} controlled scenarios x 2 checked replicas bit-exact on observations and "
       f"rewards, {no_agents} scenarios without agents, {skipped} skipped (the reference raises there too)")

@@ -80,8 +80,12 @@ if [ "$PART" = rl ]; then      # only the RL kernel statistics of the trace part
 fi
 cd $R
 if [ "$PART" = all ] || [ "$PART" = bench ]; then
-  python3 bench.py > $P/${TAG}_bench_n1.json 2> $O/bench.err                    # the driver's command (reads the fresh PMC summary)
-  python3 bench.py --network delft > $P/${TAG}_delft_bench_n1.json 2>> $O/bench.err
+  # the default command: its LAST stdout line is the compact object the driver parses, everything measured goes to bench_full.json
+  python3 bench.py > $P/${TAG}_bench_n1_line.json 2> $O/bench.err
+  cp bench_full.json $P/${TAG}_bench_n1.json
+  python3 bench.py --steps 20 --warmup 5 > $P/${TAG}_bench_driver_command_line.json 2>> $O/bench.err        # the driver's own command
+  python3 bench.py --network delft > $P/${TAG}_delft_bench_n1_line.json 2>> $O/bench.err
+  cp bench_full.json $P/${TAG}_delft_bench_n1.json
   python3 bench.py --rl --network 45_intersections --replicas 2048 > $P/${TAG}_bench_rl_config5.json 2>> $O/bench.err
   python3 bench.py --rl --network 45_intersections --replicas 2048 --history recent >> $P/${TAG}_bench_rl_config5.json 2>> $O/bench.err
   python3 bench.py --rl --randomize --network 45_intersections --replicas 2048 >> $P/${TAG}_bench_rl_config5.json 2>> $O/bench.err
