@@ -425,6 +425,22 @@ def rl_end_to_end(network, B, steps=600):
             if roll is not None:
                 res[label]["replays"], res[label]["eager_steps"] = roll.replays, roll.eager_steps
         out[pname] = res
+    # ... and over WHOLE episodes with their resets inside the timed region (every reset draws a new scenario per env on the device;
+    # the first step of an episode runs eagerly, the rest is replays): what a training loop sees per policy step
+    roll = env.capture(mlp_policy, on_step, steps_per_replay=4)
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0, n_it = time.perf_counter(), 0
+        for ep in range(2 if timed else 1):
+            env.reset(options={"randomize": True, "mode": "vectorised"}, seed=50 + ep)
+            while not roll.step():
+                pass
+            n_it += env.sim_step - 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out["end_to_end_mlp_policy"]["graph_replay_whole_episodes_with_randomised_resets"] = {
+        "value": B * n_it / dt, "unit": "env-steps/s", "steps": n_it, "us_per_iteration": dt / n_it * 1e6, "episodes": 2,
+        "replays": roll.replays, "eager_steps": roll.eager_steps, "recaptures": roll.recaptures}
     env.close()
     return out
 
