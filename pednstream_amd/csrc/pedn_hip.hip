@@ -1961,7 +1961,8 @@ int pedn_randomize_scenarios(pedn_sim* s, uint64_t seed, double link_fraction, i
     if (!s->d_max_tau && (rc = dalloc(s, 1, &s->d_max_tau)) != PEDN_OK) return rc;
     HIP_TRY(s, hipMemsetAsync(s->d_max_tau, 0, sizeof(int), s->stream));
     // recent-history mode: the cumulative_outflow ring must cover the longest shock-wave look-back drawn -- checked BEFORE the draw
-    // replaces the scenario in use: the records are drawn into a second buffer and the two are swapped only when the check has passed
+    // replaces the scenario in use: the records are drawn into a second buffer and copied over only when the check has passed (a copy,
+    // not a swap of the two pointers: DevView.prm stays what captured launches carry, pedn_rl_clock_signature)
     LinkPR* dst = s->d_prm;
     if (v.hist) {
       if (!s->d_prm_draw && (rc = dalloc(s, (size_t)v.L * v.RS, &s->d_prm_draw)) != PEDN_OK) return rc;
@@ -1975,7 +1976,7 @@ int pedn_randomize_scenarios(pedn_sim* s, uint64_t seed, double link_fraction, i
       HIP_TRY(s, hipStreamSynchronize(s->stream));
       if (mt + 2 > s->rows64[F_CO])   // the engine keeps the scenario it had
         return fail(s, PEDN_E_ARG, "a drawn shock-wave look-back (" + std::to_string(mt) + ") is longer than the cumulative_outflow ring (recent-history mode)");
-      std::swap(s->d_prm, s->d_prm_draw);
+      HIP_TRY(s, hipMemcpyAsync(s->d_prm, s->d_prm_draw, (size_t)v.L * v.RS * sizeof(LinkPR), hipMemcpyDeviceToDevice, s->stream));
     }
     v.prm = s->d_prm;
     v.pr = 1;
