@@ -64,7 +64,7 @@ def main():
     piece("four width matrices up (set_widths, before round 4)", lambda: [e.set_widths(code, net._widths[w]) for w, code in (("front", 0), ("back", 1), ("sep", 2), ("sepnp", 3))])
     piece("pedn_reset_widths (initial widths broadcast on the device)", lambda: e.reset_widths(net._widths["front"][:, 0], net._widths["back"][:, 0], net._widths["sep"][:, 0]))
     piece("first observation fetched", lambda: e.rl_observe(1, accumulate=False))
-    timed("reset(options={'randomize': True})  [reference streams]", options={"randomize": True}, seed=1)
+    timed("reset(options={'randomize': True, 'mode': 'reference'})  [reference streams]", options={"randomize": True, "mode": "reference"}, seed=1)
     T = env.simulation_steps
     t0 = time.perf_counter()
     env.reset()
