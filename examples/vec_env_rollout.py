@@ -69,6 +69,22 @@ def main():
     dt = time.perf_counter() - t0
     print(f"{n_envs * steps / dt:.3g} env-steps/s with step_device(sync=False): the host never waits; "
           f"mean return of the first agent {float(ret_a.mean()):.1f} (the same rollout)")
+
+    # and without the host in the loop at all: (policy -> env step -> reward sum) captured ONCE as a torch.cuda.CUDAGraph and replayed --
+    # the env step's launches have constant arguments because its step index lives in device memory (include/pedn.h: pedn_rl_step_clocked)
+    env.reset(options={"randomize": True, "mode": "vectorised"}, seed=2)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    ret_g = torch.zeros(n_envs, device="cuda")
+    roll = env.capture(lambda obs: low + span * torch.rand((n_envs, env.n_actions), generator=gen, device="cuda", dtype=torch.float64),
+                       lambda obs, rew: ret_g.add_(rew[:, 0]), generators=[gen], steps_per_replay=4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while env.sim_step <= steps:
+        roll.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{n_envs * (env.sim_step - 1) / dt:.3g} env-steps/s graph-replayed ({roll.replays} replays of 4 policy steps, {roll.eager_steps} eager steps); "
+          f"mean return of the first agent {float(ret_g.mean()):.1f}")
     env.close()
 
 

@@ -1012,6 +1012,7 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
 int pedn_destroy(pedn_sim* s) {
   if (!s) return PEDN_OK;
   hipSetDevice(s->device);
+  if (s->clocked) hipDeviceSynchronize();   // clocked steps may still run on a caller's stream (or in a graph being replayed there)
   if (s->stream2) hipStreamSynchronize(s->stream2);
   if (s->stream) hipStreamSynchronize(s->stream);
   for (void* p : s->allocs) hipFree(p);

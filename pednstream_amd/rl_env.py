@@ -362,6 +362,7 @@ class VecPedNetEnv:
         return {aid: obs_row[..., sl] for aid, sl in self.obs_slices.items()}
 
     def close(self):
+        self._closed = True          # a GraphedRollout of this env must not replay launches that carry the freed engine's pointers
         self.network.close()
 
 
@@ -409,6 +410,8 @@ class GraphedRollout:
         import torch
 
         env = self.env
+        if getattr(env, "_closed", False):
+            raise RuntimeError("the environment of this rollout is closed")
         if env.sim_step + env.action_gap - 1 > env.simulation_steps:
             raise IndexError("episode is over; call reset()")
         eng = env.network._flush() if not env.network.engine().rl_clocked() else env.network.engine()

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("script,args,expect", [
     ("six_node.py", [], "sum of cumulative inflow at t=499"),
     ("delft_exp.py", ["4"], "busiest link"),
-    ("vec_env_rollout.py", ["64", "40"], "agents"),
+    ("vec_env_rollout.py", ["64", "40"], "env-steps/s graph-replayed"),
     ("ensemble_delft.py", ["256"], "densest link at the end"),
     ("spike.py", ["8"], "surge demand offered at node 4"),
     ("forky_queues.py", [], "pedestrians on the bottleneck link (1,2)"),
