@@ -392,7 +392,7 @@ class GraphedRollout:
         self.graph = None
         self._actions = None           # the policy's output tensor of the captured iteration (its address is what the graph reads)
         self.replays = self.eager_steps = self.recaptures = 0
-        self._signature, self._verify = None, True
+        self._signature, self._verify, self._in_flight = None, True, False
 
     def _iteration(self, stream_ptr):
         a = self.policy_fn(self.obs)
@@ -418,6 +418,12 @@ class GraphedRollout:
         fits = env.sim_step + self.n * env.action_gap - 1 <= env.simulation_steps
         with torch.cuda.device(self.dev):
             if not eng.rl_clocked() or not fits:
+                if self._in_flight:
+                    # Replays are still running.  The eager step below ends the clocked section, which waits for the device anyway -- but
+                    # it would first enqueue the policy's kernels and a cross-stream wait behind the replays, and a second hardware queue
+                    # with a blocked wait slows every dispatch of the busy one (measured: 174 replays 44.7 -> 51.5 ms).  Wait first.
+                    torch.cuda.current_stream(self.dev).synchronize()
+                    self._in_flight = False
                 self._verify = True
                 begun = False
                 if env.sim_step > 1 and fits:
@@ -448,6 +454,7 @@ class GraphedRollout:
             if self.graph is None:
                 self._capture()
             self.graph.replay()
+            self._in_flight = True
         self.replays += 1
         env.sim_step += self.n * env.action_gap
         env.network.current_step = env.sim_step - 1
