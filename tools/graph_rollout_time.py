@@ -35,7 +35,7 @@ for name, (policy, on_step) in policies.items():
     if which not in ("all", name):
         continue
     for n in spr:
-        env.reset()
+        env.reset(options={"randomize": True, "mode": "vectorised"} if os.environ.get("GRT_RANDOMIZE") else None, seed=3)
         roll = env.capture(policy, on_step, generators=[gen], steps_per_replay=n)
         for _ in range(4):
             roll.step()
@@ -50,6 +50,6 @@ for name, (policy, on_step) in policies.items():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         steps = env.sim_step - s0
-        print(f"{B} envs, policy {name:6s}, {n:2d} policy steps per replay: {dt / steps * 1e6:6.1f} us per policy step = {B * steps / dt:.3e} env-steps/s; "
+        print(f"{B} envs{' (per-env scenarios)' if os.environ.get('GRT_RANDOMIZE') else ''}{' CLK_CHAINS=' + os.environ['PEDN_CLK_CHAINS'] if 'PEDN_CLK_CHAINS' in os.environ else ''}, policy {name:6s}, {n:2d} policy steps per replay: {dt / steps * 1e6:6.1f} us per policy step = {B * steps / dt:.3e} env-steps/s; "
               f"host {host / calls * 1e6:6.1f} us per replay call; replays {roll.replays}, eager {roll.eager_steps}", flush=True)
 env.close()
