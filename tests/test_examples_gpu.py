@@ -16,6 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("ensemble_delft.py", ["256"], "densest link at the end"),
     ("spike.py", ["8"], "surge demand offered at node 4"),
     ("forky_queues.py", [], "pedestrians on the bottleneck link (1,2)"),
+    # the reference's remaining examples (direct Network(...) construction, visualize() right after it, in-place demand edits, imposed
+    # turning fractions, a table-driven demand callable), each ending in the reference's OutputHandler files
+    ("nine_node.py", [], "turning fractions of node 4 at the last step"),
+    ("long_corridor.py", [], "long_corridor, bottleneck 2-3"),
+    ("big_network.py", ["2"], "OD pairs with paths; saved"),
+    ("melbourne.py", ["2"], "Simulation time"),
 ])
 def test_example_runs(script, args, expect, tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)
