@@ -564,10 +564,16 @@ class PedNetParallelEnv:
         OutputHandler(base_dir=base_dir, simulation_dir=simulation_dir).save_network_state(self.network)
 
     def render(self, *a, **k):
-        """Plotting (NetworkVisualizer) is outside the hot path: nothing to do without a render mode, like the reference."""
+        """Plotting (NetworkVisualizer) is outside the hot path: nothing to do without a render mode, like the reference; with one
+        (rl/rl_example.py passes render_mode="animate" and calls render() last) it warns and returns -- save() has written the files
+        the reference's visualiser reads."""
         if self.render_mode is None:
             return None
-        raise NotImplementedError("rendering is not provided; save() writes the files the reference's visualiser reads")
+        import warnings
+
+        warnings.warn("PedNetParallelEnv.render: rendering is not provided by pednstream_amd; save() writes the files the reference's "
+                      "NetworkVisualizer reads", stacklevel=2)
+        return None
 
     def close(self):
         self._vec.close()

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ("long_corridor.py", [], "long_corridor, bottleneck 2-3"),
     ("big_network.py", ["2"], "OD pairs with paths; saved"),
     ("melbourne.py", ["2"], "Simulation time"),
+    ("rl_example.py", ["120"], "Environment test completed successfully!"),
 ])
 def test_example_runs(script, args, expect, tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)] + args, capture_output=True, text=True, cwd=ROOT, timeout=600)
