@@ -14,7 +14,7 @@ from bench import replica_demand  # noqa: E402
 from pednstream_amd import NetworkEnvGenerator  # noqa: E402
 
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
-KEYS = ("PEDN_LINK_OWNER", "PEDN_INLINE_TF", "PEDN_FUSE_TP", "PEDN_STREAMS", "PEDN_PACK_BY_LOAD")
+KEYS = ("PEDN_LINK_OWNER", "PEDN_INLINE_TF", "PEDN_FUSE_TP", "PEDN_STREAMS", "PEDN_PACK_BY_LOAD", "PLAN_DEMAND_SCALE")
 tag = " ".join(f"{k[5:]}={os.environ[k]}" for k in KEYS if k in os.environ)
 lib = os.path.basename(os.environ.get("PEDN_HIP_LIB", "libpedn_hip.so"))
 for spec in sys.argv[1:]:
@@ -26,7 +26,8 @@ for spec in sys.argv[1:]:
     T = net.simulation_steps
     n = min(300, T - 142)
     for nid in net.origin_nodes:
-        net.set_demand_matrix(nid, np.stack([replica_demand(T, r) for r in range(R)]))
+        sc = float(os.environ.get("PLAN_DEMAND_SCALE", "1"))          # 12: the congested variant of the bench's demand
+        net.set_demand_matrix(nid, np.stack([replica_demand(T, r, base=5.0 * sc, peak=10.0 * sc) for r in range(R)]))
     e.run(1, 101)
     e.synchronize()
     best = 1e9
