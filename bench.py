@@ -12,29 +12,31 @@ wall time and the count of ranks that took part.  --replicas R: R replicas on ev
 shape is --replicas 512 on 8 GPUs); --total-replicas M: M replicas in all, M / N per GPU ("scaling": "strong").
 
 value = links x replicas(all ranks) x K / wall-seconds (max over ranks) of the timed region; inputs are resident in
-HBM before the region starts.  The line also carries
-  launch_plan  how pedn_run stepped (pedn_plan_info): chains of launches, and whether the link update of step t is performed by the
-               slot waves of step t + 1's node kernel (ONE launch per step) -- the default for models without device-computed
-               turning fractions, the headline among them
-  roofline     dominant kernel (node_kernel).  ONE fixed basis (`basis_kind`: "algorithmic"): `achieved` / `frac` = SURVEY 8(d)'s
-               contract bytes per launch (212 B per link-update when the node kernel performs the link update too, 164 B otherwise)
-               / the launch's duration (dispatch timestamps) vs 8 TB/s.  Beside it: `traffic` / `frac_counter` = memory-side bytes
-               per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, run as child processes BEFORE
-               this process touches the GPU (N = 1; the committed profiles/ summary of the same workload otherwise; null when there
-               is neither); `algorithmic_bytes_executed` / `frac_executed` = the contract's bytes on the paths this workload
-               really takes (the four diffusion look-backs only where get_outflow runs, widths every replica shares as scalar
-               loads, the gate record only where it changes), tallied by the oracle over the replicas cpu_baseline ran;
-               `working_set_bytes_per_step` + `fits_infinity_cache`: whether "hbm" means HBM for this batch; the whole step is
-               `whole_step_frac` (212 B per link-update) / `whole_step_frac_counter`
-  headline_long_window   the same measurement over 300 steps after 100 when the command's own --steps is shorter
+HBM before the region starts.
+
+OUTPUT.  The LAST line of stdout is ONE compact JSON object (< 4 KB: numbers and short identifiers only -- compact_line(); the driver
+keeps an 8 KB tail of stdout and parses its last line); everything measured, with the prose that says how each figure was formed, is
+written to bench_full.json beside this script.  Both carry
+  launch_plan  how pedn_run stepped (pedn_plan_info): chains of launches, whether the link update of step t is performed by the slot
+               waves of step t + 1's node kernel (ONE launch per step), how the nodes were packed into workgroups
+  roofline     dominant kernel (node_kernel).  `basis_kind` names the basis of `achieved` / `frac`: "moved" = memory-side bytes per
+               launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, run as child processes BEFORE this
+               process touches the GPU (N = 1) -- the figure the memory system can be held to; "algorithmic" without such passes
+               (N > 1, --no-live-traffic): SURVEY 8(d)'s contract bytes per launch (212 B per link-update when the node kernel
+               performs the link update too, 164 B otherwise).  Always beside it: `frac_algorithmic`, `frac_counter` (+ `traffic`),
+               `frac_executed` = the contract's bytes on the paths this workload really takes (the four diffusion look-backs only
+               where get_outflow runs, widths every replica shares as scalar loads, the gate record only where it changes), tallied
+               by the oracle over the replicas cpu_baseline ran; `fits_infinity_cache`: whether "hbm" means HBM for this batch;
+               the whole step as `whole_step_frac` (212 B per link-update) / `whole_step_frac_counter`
   cpu_baseline the C restatement under oracle/ timed on this host's cores (1 thread and all cores, CPU model stated) on a
                bounded sample of the same workload + the derived reference-Python equivalent (profiles/cpu_calibration.json)
-  extra        measured in the same run (N = 1 only; --no-extra skips them): BASELINE config #3 (delft x 1024); the headline
+  extra        measured in the same run (N = 1 only; --no-extra skips them; one figure per config in the compact line): the headline over
+               300 steps after 100 when the command's own window is shorter; BASELINE config #3 (delft x 1024); the headline
                network at 4096 replicas (working set beyond the Infinity Cache) with its own counter passes; the headline network
-               under 12 x demand (the congested regime: release draws, diffusion look-backs and divergence fire); BASELINE config
-               #2's shape (nine_intersections x 256); BASELINE config #5 (45_intersections, batched RL step, env-steps/s) with a
-               shared scenario and with per-env randomised ones, at 2048 / 4096 / 8192 envs, and SUSTAINED over whole episodes with
-               the resets inside the timed region
+               under 12 x demand; BASELINE config #2's shape (nine_intersections x 256); BASELINE config #5 (45_intersections,
+               batched RL step, env-steps/s) with a shared scenario and with per-env randomised ones, at 1024 ... 8192 envs, SUSTAINED
+               over whole episodes with the resets inside the timed region, and END TO END with a policy in the loop (random / MLP;
+               host-synchronised, chained by events, and replayed as ONE captured graph per four policy steps)
 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment starts its N ranks itself (torch.distributed.run as a
 child process, before anything touches the GPU) and exits with the child's code; a WORLD_SIZE that disagrees with --gpus
