@@ -173,3 +173,24 @@ def test_bench_rl_lines_plain_and_randomized():
         assert d["unit"] == "env-steps/s" and d["value"] > 0 and d["steps"] == 12 and d["randomized"] == bool(extra)
         assert 0 < d["whole_step_frac"] < 1 and d["device_ms_per_step"] > 0
         assert ("randomized_reset_s" in d) == bool(extra)
+
+
+def test_bench_rl_end_to_end_lines_at_a_small_size():
+    """bench.py --rl --rl-end-to-end (what rides in the driver's line as extra.config5....end_to_end_*): both policies, the three loops
+    (host-synchronised, chained by events, graph-replayed) and the whole-episode figure, at 128 envs."""
+    import json
+    import subprocess
+
+    pytest.importorskip("torch")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rl", "--rl-end-to-end", "--network", "45_intersections", "--replicas", "128",
+                          "--steps", "60"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for policy in ("end_to_end_random_policy", "end_to_end_mlp_policy"):
+        for loop in ("host_synchronised_every_step", "streams_chained_by_events", "graph_replay"):
+            assert d[policy][loop]["value"] > 0 and d[policy][loop]["steps"] >= 48, (policy, loop)
+        assert d[policy]["graph_replay"]["replays"] >= 12 and d[policy]["graph_replay"]["eager_steps"] == 1
+    # the MLP policy is deterministic: the two eager loops run the same rollout
+    assert d["end_to_end_mlp_policy"]["host_synchronised_every_step"]["mean_return"] == d["end_to_end_mlp_policy"]["streams_chained_by_events"]["mean_return"]
+    ep = d["end_to_end_mlp_policy"]["graph_replay_whole_episodes_with_randomised_resets"]
+    assert ep["steps"] == 1400 and ep["recaptures"] == 0 and ep["value"] > 0
