@@ -295,7 +295,8 @@ int pedn_get_od_weights_per_replica(pedn_sim* sim, double* w);
  * re-derived, link.py:58-63,83-86,380), bit 1 OD weights (generate_random_od_flows :224-259: U(1, 10) per OD pair, constant over
  * the episode), bit 2 origin demand (generate_random_demand_params :183-222 + the series of od_manager.py:92-155 as pedn_draw_demand)
  * for the n_origins nodes listed.  Philox4x32-10 keyed by (seed, global replica id): a function of the seed, independent of how the
- * ensemble is sharded; the same distributions as the reference's randomisers, NOT numpy's stream (distribution-tested only).
+ * ensemble is sharded; the same distributions as the reference's randomisers, NOT numpy's stream: pinned bit for bit by
+ * the CPU restatement oracle/rand_contract.py and distribution-tested against the numpy generator it replaces.
  * Asynchronous; call pedn_reset afterwards. */
 int pedn_randomize_scenarios(pedn_sim* sim, uint64_t seed, double link_fraction, int32_t what, const int32_t* origin_nodes,
                              int32_t n_origins);
@@ -372,7 +373,7 @@ void* pedn_rl_device_ptr(pedn_sim* sim, int32_t which);
  *   pattern 2 sudden_demand:  pattern 0 plus `spike_height` for spike_start <= t < spike_start + spike_len
  * Arrays are [n_replicas] for ONE origin node.  The Poisson draws are keyed (seed, global replica id, node, t) with
  * Philox4x32-10 and inverted by sequential search; this is a generator of its own (same distributions as the reference,
- * not numpy's stream) and is pinned by distribution tests only. */
+ * not numpy's stream), pinned bit for bit by oracle/rand_contract.py (glibc's exp on both sides). */
 int pedn_draw_demand(pedn_sim* sim, int32_t node, uint64_t seed, const int32_t* pattern, const double* base, const double* peak,
                      const int32_t* spike_start, const int32_t* spike_len, const double* spike_height);
 

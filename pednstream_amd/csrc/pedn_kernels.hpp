@@ -1537,12 +1537,13 @@ __global__ void draw_demand_kernel(double* dst, size_t row, int T1, int R, int R
     if (pat == 1) val = base[r];
     else if (t < T) {
       const double w = (double)T / 20.0, a = ((double)t - (double)T / 4.0), b = ((double)t - 3.0 * (double)T / 4.0);
-      const double lam = base[r] + peak[r] * exp(-(a * a) / (2.0 * w * w)) + peak[r] * exp(-(b * b) / (2.0 * w * w));
+      // (pedn_exp, not the device library's exp: the series is pinned bit for bit by a CPU restatement, oracle/rand_contract.py)
+      const double lam = base[r] + peak[r] * pedn_exp(-(a * a) / (2.0 * w * w)) + peak[r] * pedn_exp(-(b * b) / (2.0 * w * w));
       // Poisson(lam) by inversion: sequential search from 0 with one 53-bit uniform (lam stays below ~100 here)
       uint32_t c[4] = {(uint32_t)t, node, 0x50u, replica_offset + (uint32_t)r};
       philox4x32_10(c, k0, k1);
       const double u = (double)((((uint64_t)c[0] << 32) | c[1]) >> 11) * 0x1p-53;
-      double p = exp(-lam), cdf = p;
+      double p = pedn_exp(-lam), cdf = p;
       int k = 0;
       while (u > cdf && k < 1000) {
         ++k;
@@ -1725,11 +1726,11 @@ __global__ void rand_demand_kernel(double* dst, const int32_t* rows, const int32
     if (pat == 1) val = base;
     else if (t < T) {
       const double w = (double)T / 20.0, x = ((double)t - (double)T / 4.0), y = ((double)t - 3.0 * (double)T / 4.0);
-      const double lam = base + peak * exp(-(x * x) / (2.0 * w * w)) + peak * exp(-(y * y) / (2.0 * w * w));
+      const double lam = base + peak * pedn_exp(-(x * x) / (2.0 * w * w)) + peak * pedn_exp(-(y * y) / (2.0 * w * w));
       uint32_t c[4] = {(uint32_t)t, node, 0x50u, replica_offset + (uint32_t)r};
       philox4x32_10(c, k0, k1);
       const double u = (double)((((uint64_t)c[0] << 32) | c[1]) >> 11) * 0x1p-53;
-      double p = exp(-lam), cdf = p;
+      double p = pedn_exp(-lam), cdf = p;
       int k = 0;
       while (u > cdf && k < 1000) {
         ++k;

@@ -407,3 +407,52 @@ def test_unseeded_vectorised_resets_draw_fresh_scenarios():
     env.reset(options={"randomize": True, "mode": "vectorised"}, seed=a[0])      # and the kept seed reproduces the draw
     assert np.array_equal(env.scenarios.kc, a[1]) and np.array_equal(env.scenarios.od_w, a[3])
     env.close()
+
+
+def test_device_randomiser_equals_its_cpu_restatement_bit_for_bit():
+    """What `mode='vectorised'` draws is the device's own contract (not numpy's stream): oracle/rand_contract.py restates it -- corridor
+    selection, factors and floors, OD weights, demand pattern / levels / spike, the Poisson series with glibc's exp -- and the kernels
+    must agree with it BIT FOR BIT for every replica checked, whatever the shard (global replica ids key the draws); the same for
+    pedn_draw_demand with explicit parameters."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(DATA)), "oracle"))
+    import rand_contract as rc
+    from pednstream_amd.rl_env import VecPedNetEnv
+
+    B, off, seed = 24, 1000, 0x1234567890ABCDEF
+    env = VecPedNetEnv("45_intersections", n_envs=B, obs_mode="option3", data_dir=DATA, seed=9, replica_offset=off)
+    env.reset(options={"randomize": True, "mode": "vectorised"}, seed=seed)
+    net, sc, e = env.network, env.scenarios, env.network.engine()
+    m = e.model
+    L, T = e.n_links, int(m["T"])
+    rev = np.asarray(m["link_rev"])
+    corridors = [(l, int(rev[l])) for l in range(L) if l < rev[l]]
+    base = {l: (float(m["link_kc"][l]), float(m["link_kj"][l]), float(m["link_vf"][l])) for l in range(L)}
+    kc, kj, vf, od_w = sc.kc, sc.kj, sc.vf, sc.od_w
+    origins = [n for n in net.nodes.values() if n.virtual_incoming_link is not None and n.node_id in net.origin_nodes]
+    changed = 0
+    for r in (0, 1, 7, B - 1):
+        want = rc.link_params(seed, off + r, corridors, base)
+        for l in range(L):
+            assert (kc[l, r], kj[l, r], vf[l, r]) == want[l], (r, l)
+        changed += sum(1 for l in range(L) if want[l] != base[l])
+        for od in range(od_w.shape[0]):
+            assert od_w[od, r] == rc.od_weight(seed, off + r, od), (r, od)
+        for node in origins:
+            pars = rc.demand_params(seed, off + r, node.index, T)
+            series = rc.demand_series(seed, off + r, node.index, T, *pars)
+            assert np.array_equal(e.get_demand(node.index, r), np.array(series)), (r, node.node_id, pars)
+    assert changed > 0
+    # pedn_draw_demand with explicit per-replica parameters: the same series function
+    rng = np.random.default_rng(2)
+    pattern = rng.integers(0, 3, B).astype(np.int32)
+    lo, pk = rng.uniform(2, 10, B), rng.uniform(10, 30, B)
+    st, ln, ht = rng.integers(0, T - 30, B).astype(np.int32), rng.integers(10, 20, B).astype(np.int32), rng.integers(20, 50, B).astype(np.float64)
+    node = origins[0]
+    e.draw_demand(node.index, 77, pattern, lo, pk, st, ln, ht)
+    for r in (0, 5, B - 1):
+        series = rc.demand_series(77, off + r, node.index, T, int(pattern[r]), float(lo[r]), float(pk[r]), int(st[r]), int(ln[r]), float(ht[r]))
+        assert np.array_equal(e.get_demand(node.index, r), np.array(series)), r
+    env.close()

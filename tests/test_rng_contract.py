@@ -80,3 +80,48 @@ def test_exp_restatement_matches_libm_exp():
     else:       # another glibc may round a few arguments differently; the restatement itself is < 1 ulp
         assert all(abs(L.pedn_oracle_exp(float(x)) - np.exp(x)) <= np.spacing(np.exp(x)) for x in xs[::50])
     assert L.pedn_oracle_exp(0.0) == 1.0
+
+
+def test_device_randomiser_contract_draws_the_reference_ranges():
+    """oracle/rand_contract.py (the CPU restatement the device randomiser is pinned against, tests/test_gpu_scenarios.py) on its own:
+    exactly int(P * fraction) corridors per replica, both links of a chosen corridor scaled from their own base values within the
+    reference's ranges and floors (env_loader.py:363-424), OD weights in [1, 10) (:224-259), demand parameters in their ranges (:183-222),
+    a constant pattern's series constant, the others non-negative integers that stop at T."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import rand_contract as rc
+
+    P = 37
+    corridors = [(2 * p, 2 * p + 1) for p in range(P)]
+    base = {l: (2.0 + 0.1 * (l % 3), 6.0 + 0.5 * (l % 2), 1.1 + 0.01 * l) for l in range(2 * P)}
+    seen = np.zeros(P, dtype=int)
+    for g in range(200):
+        got = rc.link_params(99, g, corridors, base)
+        touched = 0
+        for p, (a, b) in enumerate(corridors):
+            for l in (a, b):
+                kc, kj, vf = got[l]
+                assert 0.6 * base[l][2] <= vf <= base[l][2] and kj >= 2.0 * kc - 1e-12 and kc >= 0.5
+                assert max(0.5, 0.6 * base[l][0]) - 1e-12 <= kc <= 1.2 * base[l][0] + 1e-12
+            # a corridor's two links share the decision, and a chosen corridor may still draw "neither part" (1/4 of the time)
+            assert (got[a] != base[a]) == (got[b] != base[b])
+            touched += got[a] != base[a]
+            seen[p] += got[a] != base[a]
+        assert touched <= int(P * 0.2)
+    assert seen.min() > 0 and seen.max() < 80                      # every corridor is picked sometimes, none always
+    w = [rc.od_weight(5, g, od) for g in range(50) for od in range(6)]
+    assert 1.0 <= min(w) and max(w) < 10.0 and len(set(w)) == len(w)
+    T, patterns = 500, set()
+    for g in range(60):
+        pat, lo, pk, start, length, height = rc.demand_params(7, g, 12, T)
+        patterns.add(pat)
+        assert 2.0 <= lo < 10.0 and pk >= lo + 5.0 and 10 <= length < 20 and 0 <= start < T - length and 20.0 <= height < 50.0
+        s = rc.demand_series(7, g, 12, T, pat, lo, pk, start, length, height)
+        assert len(s) == T + 1 and min(s) >= 0.0
+        if pat == 1:
+            assert set(s) == {lo}
+        else:
+            assert s[T] == 0.0 and all(x == int(x) for x in s) and 0.3 * lo * T < sum(s) < (lo + 2 * pk + 60) * T
+    assert patterns == {0, 1, 2}
