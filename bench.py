@@ -732,13 +732,13 @@ def compact_line(out):
                 c5 = {"unit": "env-steps/s"}
                 for k in ("plain", "randomized"):
                     if k in v:
-                        c5[k] = _pick(v[k], ("value", "ms_per_step", "whole_step_frac"))
-                if "by_n_envs_recent_history" in v:
+                        c5[k] = _pick(v[k], ("value", "ms_per_step", "whole_step_frac")) if "error" not in v[k] else {"error": str(v[k]["error"])[:60]}
+                if "by_n_envs_recent_history" in v and "error" not in v["by_n_envs_recent_history"]:
                     c5["by_n_envs"] = {n: _sig(x["value"], 4) for n, x in v["by_n_envs_recent_history"].items()}
                 for k in ("end_to_end_random_policy", "end_to_end_mlp_policy"):
                     if k in v:
                         c5[k] = {kk: _sig(x["value"], 4) for kk, x in v[k].items() if isinstance(x, dict) and "value" in x}
-                if "sustained" in v:
+                if "sustained" in v and "error" not in v["sustained"]:
                     c5["sustained"] = {kk: _sig(x["value"], 4) for kk, x in v["sustained"].items()}
                 e2[name] = c5
             else:
@@ -864,18 +864,31 @@ def main():
         # BASELINE config #2's shape
         extra("nine_x256", lambda: variant("nine_intersections", replicas=256, steps=max(args.steps, 200), warmup=max(args.warmup, 100)))
         # BASELINE config #5: the batched RL env step on 45_intersections, shared scenario and per-env randomised scenarios
-        extra("config5_rl_45int_x2048", lambda: {
-            "plain": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=False),
-            "randomized": measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=True),
+        def config5():
+            """Every part on its own: a part that fails is reported in its place and costs neither the others nor the headline."""
+            c5 = {}
+
+            def part(name, fn):
+                try:
+                    r = fn()
+                    c5.update(r) if name is None else c5.__setitem__(name, r)
+                except Exception as exc:    # noqa: BLE001
+                    c5[name or "end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
+
+            part("plain", lambda: measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=False))
+            part("randomized", lambda: measure_rl("45_intersections", 2048, args.steps, args.warmup, "full", randomized=True))
             # where the env step stops being latency-bound: more envs per launch (recent-history mode: 8192 envs are 16 GB)
-            "by_n_envs_recent_history": {str(n): {k: v for k, v in measure_rl("45_intersections", n, args.steps, args.warmup, "recent", randomized=False).items()
-                                                  if k in ("value", "unit", "device_ms_per_step", "whole_step_frac", "steps")}
-                                         for n in (1024, 2048, 4096, 8192)},   # 1024 envs: the single-launch plan with helper waves + the observations
+            part("by_n_envs_recent_history", lambda: {
+                str(n): {k: v for k, v in measure_rl("45_intersections", n, args.steps, args.warmup, "recent", randomized=False).items()
+                         if k in ("value", "unit", "device_ms_per_step", "whole_step_frac", "steps")} for n in (1024, 2048, 4096, 8192)})
             # a policy in the loop (torch on the same GPU): what a rollout sees end to end, eager and as a replayed graph
-            **rl_end_to_end("45_intersections", 2048),
+            part(None, lambda: rl_end_to_end("45_intersections", 2048))
             # whole episodes WITH their resets (rl/pz_pednet_env.py:143-193 resets every episode)
-            "sustained": {f"{mode}_{hist}": sustained_rl("45_intersections", 2048, hist, mode)
-                          for hist in ("full", "recent") for mode in ("plain", "vectorised", "reference")}})
+            part("sustained", lambda: {f"{mode}_{hist}": sustained_rl("45_intersections", 2048, hist, mode)
+                                       for hist in ("full", "recent") for mode in ("plain", "vectorised", "reference")})
+            return c5
+
+        extra("config5_rl_45int_x2048", config5)
     if rank == 0:
         # everything measured goes to a file beside the script; the LAST line of stdout is the compact headline object (< 4 KB)
         try:
