@@ -2292,7 +2292,8 @@ int pedn_rl_clocked(pedn_sim* s) { return s && s->clocked ? 1 : 0; }
 // switches -- not valid_hi, which a clocked launch takes from the clock), the RL view, and what selects kernels and grids.
 uint64_t pedn_rl_clock_signature(pedn_sim* s) {
   if (!s) return 0;
-  DevView v = s->v;
+  DevView v;
+  memcpy(&v, &s->v, sizeof v);   // byte image, padding included (see below)
   v.valid_hi = 0;
   v.rl_actions = nullptr;
   uint64_t h = 1469598103934665603ull;   // FNV-1a
@@ -2301,10 +2302,9 @@ uint64_t pedn_rl_clock_signature(pedn_sim* s) {
     for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
   };
   static_assert(std::is_trivially_copyable<DevView>::value && std::is_trivially_copyable<RlView>::value, "hashed as bytes");
-  DevView z;
-  memset(&z, 0, sizeof z);       // (padding bytes of the copy are whatever the copy left there: hash field images laid over zeros)
-  memcpy(&z, &v, sizeof v);
-  mix(&z, sizeof z);
+  // (hashed as bytes, padding included: s->v lives in the value-initialised pedn_sim and is only ever changed field by field, so
+  // its padding keeps the image it was created with; a spurious difference would cost one more capture, never a stale graph)
+  mix(&v, sizeof v);
   mix(&s->rl, sizeof s->rl);
   const int64_t sel[8] = {s->rl_fold, s->n_tf_heavy_quads, s->n_blocks, (int64_t)s->node_lds, s->max_degree, s->node_lp, s->fuse_tp, s->fuse_obs};
   mix(sel, sizeof sel);
@@ -2328,21 +2328,22 @@ void* pedn_rl_device_ptr(pedn_sim* s, int32_t which) {
 int pedn_device_math(int32_t device, int32_t op, int32_t n, const double* a, const double* b, uint64_t seed, double* out) {
   if (n <= 0 || !a || !out) return fail(nullptr, PEDN_E_ARG, "bad argument");
   HIP_TRY(nullptr, hipSetDevice(device));
-  double *da = nullptr, *db = nullptr, *dout = nullptr;
-  HIP_TRY(nullptr, hipMalloc((void**)&da, (size_t)n * 8));
-  HIP_TRY(nullptr, hipMalloc((void**)&dout, (size_t)n * 8));
-  HIP_TRY(nullptr, hipMemcpy(da, a, (size_t)n * 8, hipMemcpyHostToDevice));
+  struct Buf {   // freed on every way out
+    double* p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+  } da, db, dout;
+  HIP_TRY(nullptr, hipMalloc((void**)&da.p, (size_t)n * 8));
+  HIP_TRY(nullptr, hipMalloc((void**)&dout.p, (size_t)n * 8));
+  HIP_TRY(nullptr, hipMemcpy(da.p, a, (size_t)n * 8, hipMemcpyHostToDevice));
   if (b) {
-    HIP_TRY(nullptr, hipMalloc((void**)&db, (size_t)n * 8));
-    HIP_TRY(nullptr, hipMemcpy(db, b, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(nullptr, hipMalloc((void**)&db.p, (size_t)n * 8));
+    HIP_TRY(nullptr, hipMemcpy(db.p, b, (size_t)n * 8, hipMemcpyHostToDevice));
   }
-  hipLaunchKernelGGL(device_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, n, (const double*)da, (const double*)db,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), dout);
+  hipLaunchKernelGGL(device_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, n, (const double*)da.p, (const double*)db.p,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), dout.p);
+  HIP_TRY(nullptr, hipGetLastError());
   HIP_TRY(nullptr, hipDeviceSynchronize());
-  HIP_TRY(nullptr, hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
-  hipFree(da);
-  hipFree(dout);
-  if (db) hipFree(db);
+  HIP_TRY(nullptr, hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
   return PEDN_OK;
 }
 

@@ -276,9 +276,10 @@ class VecPedNetEnv:
 
         ``sync=False``: no host synchronisation at all -- the engine's stream waits (on the device) for the caller's current torch
         stream, and that stream then waits for the engine's: the policy's kernels, the env step and whatever consumes the observations
-        are chained by events, and the host runs ahead enqueueing the next step (45_intersections x 2048 envs end to end, after
-        warm-up: 68-71 -> 62-64 us per step with a random torch policy, 168-170 -> 154-155 with a small MLP: the loop is bound by
-        torch's own per-op launch overhead).  Work issued on OTHER torch streams must be ordered by the caller.
+        are chained by events, and the host runs ahead enqueueing the next step (45_intersections x 2048 envs end to end:
+        70.7 -> 66.4 us per step with a random torch policy, 172 -> 163 with a small MLP: the loop is bound by torch's own per-op
+        launch overhead -- ``capture`` below takes the host out of it: 40 / 61 us, profiles/r05_graph_rollout.txt).  Work issued on
+        OTHER torch streams must be ordered by the caller.
 
         torch and the engine share one HIP runtime whichever is imported first (``engine._bind_hip_runtime``)."""
         import torch
