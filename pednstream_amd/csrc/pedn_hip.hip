@@ -563,7 +563,12 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     for (int f = 0; f < 7; ++f) need += (size_t)s->rows64[f] * (f < 4 ? v.Lall : L) * RS * 8;
     for (int g = 0; g < 6; ++g) need += (size_t)s->rows32[g] * L * RS * 4;
     size_t free_b = 0, total_b = 0;
-    hipMemGetInfo(&free_b, &total_b);
+    const hipError_t mi = hipMemGetInfo(&free_b, &total_b);
+    if (mi != hipSuccess) {
+      std::string msg = std::string("hipMemGetInfo: ") + hipGetErrorString(mi);
+      pedn_destroy(s);
+      return fail(nullptr, PEDN_E_DEVICE, msg);
+    }
     if (need + (256u << 20) > free_b) {
       std::string msg = "not enough HBM: need " + std::to_string(need >> 20) + " MiB, free " + std::to_string(free_b >> 20) + " MiB";
       pedn_destroy(s);
