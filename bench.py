@@ -12,7 +12,8 @@ wall time and the count of ranks that took part.  --replicas R: R replicas on ev
 shape is --replicas 512 on 8 GPUs); --total-replicas M: M replicas in all, M / N per GPU ("scaling": "strong").
 
 value = links x replicas(all ranks) x K / wall-seconds (max over ranks) of the timed region; inputs are resident in
-HBM before the region starts.
+HBM before the region starts.  The region: barrier + synchronize | clock starts | K steps | synchronize | clock stops | barrier;
+every rank times its own K steps to completion and the job's time is the MAX over ranks.
 
 OUTPUT.  The LAST line of stdout is ONE compact JSON object (< 4 KB: numbers and short identifiers only -- compact_line(); the driver
 keeps an 8 KB tail of stdout and parses its last line); everything measured, with the prose that says how each figure was formed, is
@@ -522,8 +523,16 @@ def measure(args, network, dist, rank, local_rank, world, demand_scale=1.0):
     t0 = time.perf_counter()
     advance(args.steps)
     dev_ms = e.timer_end()          # HIP events on the engine's stream
-    barrier()
+    e.synchronize()
+    if dist is not None and args.backend == "nccl":
+        import torch
+        torch.cuda.synchronize()
+    # this rank's K steps have completed: its clock stops HERE, the closing barrier follows, and the MAX over ranks below is the
+    # job's time.  (Rounds 1-4 stopped the clock behind the barrier: an RCCL barrier is a small all-reduce plus a stream
+    # synchronisation, 0.15-0.25 ms -- a third of a 20-step region of 31 us steps, charged to the step only at N > 1, where it read
+    # as a scaling loss of a path that has no collective.)
     wall = time.perf_counter() - t0
+    barrier()
     ranks_seen = 1
     if dist is not None:
         import torch
