@@ -733,7 +733,10 @@ __device__ __noinline__ bool lp_solve(double* T, int32_t* B, int m, const double
 // slot wave k (where that wave would compute its own) while the slot wave does its loads, link update and flows; they meet once, right
 // before the slot wave multiplies its row into the sending flow.  A step of a small batch is as long as its slowest wave's chain: the
 // row (~5 us) and the rest (~5 us) side by side instead of in a row.
-template <bool PR, bool LP, bool HIST, int MD, bool LU, bool TF, bool HELP = false>
+// CLK: t and vhi were loaded from the device clock by the caller (node_kernel<.., CLK>); the horizon guard on t sits BEHIND the slot
+// record's first load (below), so that the clock's scalar load and the record's load are in flight together -- a guard at the top of
+// the kernel put the clock in front of the record as one more serial memory latency of every wave.
+template <bool PR, bool LP, bool HIST, int MD, bool LU, bool TF, bool HELP = false, bool CLK = false>
 __device__ __forceinline__ void node_step(const DevView& v, const int t, const int vhi, const int bx, const int by, double* const pedn_lds) {
   double* const sR = pedn_lds;                          // [8][64] receiving flow of each wave's outgoing link
   double* const sS = pedn_lds + 8 * 64;                 // [8][64] LP only: sending flow of each wave's incoming link
@@ -753,6 +756,13 @@ __device__ __forceinline__ void node_step(const DevView& v, const int t, const i
   const int node = W.node, slot = W.slot, base = W.base, m = W.m;
   const bool active = node >= 0;
   PH(1, lane + node);
+  if (CLK) {
+    // a clocked launch replayed beyond the horizon: uniform over the grid.  (node >= -1 always: the term only makes the guard depend on
+    // the record, or the compiler sinks the record's load behind the branch and the two loads are serial again; an asm barrier instead
+    // costs the per-replica-parameter instantiations 6-16 vector spills)
+    if (t >= v.T1 + (node < -1 ? 1 : 0)) return;
+    if (bx == 0 && by == 0 && threadIdx.x == 0) v.clock[1] = t;   // the step of the launch behind this one (see node_clock)
+  }
   uint32_t fl = 0;
   double s_i = 0.0, r_i = 0.0, qo = 0.0, qi = 0.0, co_prev = 0.0, ci_prev = 0.0;
   int lin = 0, lout = 0, kind = 0;
@@ -1064,9 +1074,8 @@ constexpr int node_kernel_waves() {
 struct StepClock { int t, vhi; };
 __device__ __forceinline__ StepClock node_clock(const DevView& v) {
   StepClock c;
-  c.t = v.clock[0];   // wave-uniform: two scalar loads beside the slot record's
+  c.t = v.clock[0];   // wave-uniform: two scalar loads beside the slot record's (node_step<.., CLK> checks t and writes clock[1])
   c.vhi = v.clock[2];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) v.clock[1] = c.t;
   return c;
 }
 
@@ -1079,8 +1088,7 @@ __global__ __launch_bounds__(512, (node_kernel_waves<PR, LP, MD, TF, CLK>())) vo
   extern __shared__ double pedn_lds[];
   if (CLK) {
     const StepClock c = node_clock(v);
-    if (c.t >= v.T1) return;   // a clocked launch replayed beyond the horizon: uniform over the grid
-    node_step<PR, LP, HIST, MD, LU, TF>(v, c.t, c.vhi, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
+    node_step<PR, LP, HIST, MD, LU, TF, false, true>(v, c.t, c.vhi, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
   } else {
     node_step<PR, LP, HIST, MD, LU, TF>(v, t, v.valid_hi, (int)blockIdx.x, (int)blockIdx.y, pedn_lds);
   }
