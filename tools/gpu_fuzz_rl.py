@@ -39,6 +39,10 @@ for seed in range(lo, hi):
     except KeyError:
         skipped += 1
         continue
+    if flatten_network(net)["max_degree"] > 8:   # kernel limit (PEDN_MAX_DEGREE): pedn_create refuses such a junction
+        skipped += 1
+        net.close()
+        continue
     rng = np.random.default_rng(seed)
     mode = ["option1", "option2", "option3", "option4", "option5"][rng.integers(0, 5)]
     normalize, gap = bool(rng.integers(0, 2)), int(rng.integers(1, 3))
