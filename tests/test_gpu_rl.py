@@ -439,3 +439,26 @@ def test_clocked_step_argument_errors_and_horizon_guard():
     assert np.array_equal(e.read_block(2, 0, 7), ref) and e.error_flags()[0] == 0
     assert e.read_block(2, T, T + 1).sum() > 0
     env.close()
+
+
+def test_reference_reset_determinism_script_shapes():
+    """rl/test_reset_determinism.py:29-83,294-330 restated: 45_intersections, option3 without normalisation, five episodes of
+    reset(options={'randomize': True}) + empty action dicts.  What the reference's committed run pins
+    (rl/outputs/reset_determinism_test/statistics.json): one agent, gate_24, 20 observation values, 5 episodes -- and 701 observations
+    per episode (:59-77); its episodes differ by design (max_difference 86.0), so do these."""
+    env = PedNetParallelEnv("45_intersections", normalize_obs=False, obs_mode="option3", render_mode=None, verbose=False)
+    assert env.possible_agents == ["gate_24"] and env.observation_space("gate_24").shape == (20,)
+    episodes = []
+    for ep in range(5):
+        obs, infos = env.reset(options={"randomize": True})
+        states = [obs["gate_24"].copy()]
+        done = False
+        while not done:
+            obs, rewards, terms, truncs, infos = env.step({})
+            states.append(obs["gate_24"].copy())
+            done = any(terms.values()) or any(truncs.values())
+        episodes.append(np.stack(states))
+    assert all(e.shape == (701, 20) and np.isfinite(e).all() for e in episodes)
+    diffs = [np.abs(episodes[i] - episodes[j]).max() for i in range(5) for j in range(i)]
+    assert min(diffs) > 0.0, diffs          # every pair of episodes differs somewhere
+    env.close()
