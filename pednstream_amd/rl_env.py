@@ -492,6 +492,7 @@ class PedNetParallelEnv:
         self.possible_agents = list(self._vec.possible_agents)
         self.simulation_steps = self._vec.simulation_steps
         self._cumulative_rewards = {a: 0.0 for a in self.possible_agents}
+        self._action_spaces, self._observation_spaces = {}, {}
         self.render_mode = render_mode
         self.dataset = dataset
 
@@ -508,14 +509,18 @@ class PedNetParallelEnv:
         controlled link for a gater."""
         if agent not in self._vec.action_slices:
             raise ValueError(f"Agent {agent} not found in action spaces")
-        sl = self._vec.action_slices[agent]
-        return _make_box(self._vec.action_low[sl], self._vec.action_high[sl], (sl.stop - sl.start,))
+        if agent not in self._action_spaces:      # one object per agent (rl/pz_pednet_env.py:136 caches; PettingZoo's API test asserts identity)
+            sl = self._vec.action_slices[agent]
+            self._action_spaces[agent] = _make_box(self._vec.action_low[sl], self._vec.action_high[sl], (sl.stop - sl.start,))
+        return self._action_spaces[agent]
 
     def observation_space(self, agent):
         if agent not in self._vec.obs_slices:
             raise ValueError(f"Agent {agent} not found in observation spaces")
-        sl = self._vec.obs_slices[agent]
-        return _make_box(-np.inf, np.inf, (sl.stop - sl.start,))
+        if agent not in self._observation_spaces:
+            sl = self._vec.obs_slices[agent]
+            self._observation_spaces[agent] = _make_box(-np.inf, np.inf, (sl.stop - sl.start,))
+        return self._observation_spaces[agent]
 
     def _dict(self, row):
         return {a: np.array(row[sl]) for a, sl in self._vec.obs_slices.items()}

@@ -462,3 +462,31 @@ def test_reference_reset_determinism_script_shapes():
     diffs = [np.abs(episodes[i] - episodes[j]).max() for i in range(5) for j in range(i)]
     assert min(diffs) > 0.0, diffs          # every pair of episodes differs somewhere
     env.close()
+
+
+def test_pettingzoo_parallel_api_checks_restated():
+    """rl/test_pz_api.py:18-47 runs pettingzoo.test.parallel_api_test(env, num_cycles=100) on nine_intersections; pettingzoo is not in
+    this image, so the checks that function makes are restated: dict-of-agents returns keyed by the live agents, the agent set inside
+    possible_agents, the space accessors returning the SAME object every call, observations inside their spaces, two resets."""
+    env = PedNetParallelEnv(dataset="nine_intersections", normalize_obs=True)
+    rng = np.random.default_rng(0)
+    assert len(env.possible_agents) > 0
+    for _ in range(2):
+        obs, infos = env.reset()
+        assert isinstance(obs, dict) and isinstance(infos, dict)
+        assert set(obs) == set(env.agents) == set(infos)
+        live = set(env.agents)
+        for _cycle in range(100):
+            actions = {a: rng.uniform(env.action_space(a).low, env.action_space(a).high).astype(np.float32) for a in env.agents}
+            obs, rew, terminated, truncated, info = env.step(actions)
+            for v in (obs, rew, terminated, truncated, info):
+                assert isinstance(v, dict) and set(v) == live
+            assert set(env.agents) <= set(env.possible_agents) and set(env.agents) == live
+            for a in env.agents:
+                assert env.observation_space(a) is env.observation_space(a) and env.action_space(a) is env.action_space(a)
+                o = obs[a]
+                assert o.dtype == np.float32 and o.shape == env.observation_space(a).shape and env.observation_space(a).contains(o)
+                assert isinstance(rew[a], float) and terminated[a] is False and truncated[a] is False
+    with pytest.raises(ValueError):
+        env.observation_space("nobody")
+    env.close()
