@@ -494,6 +494,11 @@ class PedNetParallelEnv:
         self._cumulative_rewards = {a: 0.0 for a in self.possible_agents}
         self._action_spaces, self._observation_spaces = {}, {}
         self.render_mode = render_mode
+        # what the reference's trainers and rule-based agents read off the env (rl/rl_utils.py:133,197: env.obs_builder.features_per_link;
+        # rl/agents/rule_based.py:189, rl/train_rl.py:177: env.obs_mode)
+        self.obs_mode, self.normalize_obs, self.action_gap = obs_mode, bool(normalize_obs), int(action_gap)
+        self.obs_builder = type("ObservationBuilderView", (), {"features_per_link": self._vec.features_per_link, "obs_mode": obs_mode,
+                                                               "normalize": bool(normalize_obs)})()
         self.dataset = dataset
 
     @property

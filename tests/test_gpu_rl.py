@@ -471,6 +471,8 @@ def test_pettingzoo_parallel_api_checks_restated():
     env = PedNetParallelEnv(dataset="nine_intersections", normalize_obs=True)
     rng = np.random.default_rng(0)
     assert len(env.possible_agents) > 0
+    # what the reference's trainers / rule-based agents read off the env (rl/rl_utils.py:133, rl/agents/rule_based.py:189)
+    assert env.obs_mode == "option1" and env.obs_builder.features_per_link == 3 and env.normalize_obs is True
     for _ in range(2):
         obs, infos = env.reset()
         assert isinstance(obs, dict) and isinstance(infos, dict)
