@@ -253,7 +253,7 @@ int pedn_profile_run(pedn_sim* sim, int32_t t0, int32_t t1, float ms[3], int32_t
 int pedn_profile_timeline(pedn_sim* sim, int32_t t0, int32_t t1, float* out, int32_t capacity, int32_t* n_rows, int32_t* chains);
 
 /* launch plan of pedn_run for long ranges: 1 = one chain of launches on the engine's stream, 2 = the halves of the replicas as two
- * chains on two streams (the default from 1024 replicas; replicas are independent, results are the same).  The two streams are probed
+ * chains on two streams (the default from 640 replicas -- the halves are whole 128-replica segments, 640 = 384 + 256; replicas are independent, results are the same).  The two streams are probed
  * to run side by side (pedn_plan_info); when the runtime cannot provide two independent queues the plan falls back to one chain. */
 int pedn_set_streams(pedn_sim* sim, int32_t n);
 /* The launch plan of pedn_run: info[0] = chains (1 | 2), info[1] = 1 when the link update is performed by the next step's node kernel

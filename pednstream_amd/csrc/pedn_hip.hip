@@ -874,11 +874,11 @@ int pedn_create(const pedn_model_desc* m, int32_t n_replicas, int32_t replica_of
     if (const char* f = getenv("PEDN_FUSE_TP")) s->fuse_tp = atoi(f) != 0;
     if (const char* f = getenv("PEDN_FUSE_OBS")) s->fuse_obs = atoi(f) != 0;
     for (SlotRec& R : rec) { R.act = -1; R.lp = -1; }
-    // two chains of launches (one per half of the replicas) in pedn_run; PEDN_STREAMS=1|2, pedn_set_streams.  Default: models
-    // with dynamic turning-fraction rows from 1024 replicas -- their second launch is few long waves at 4 waves per SIMD, and the
-    // other half's node_kernel fills the machine meanwhile (delft x 1024: 51.7 -> 45.3 us per step).  Without such rows the gain
-    // is smaller (melbourne 38.8 -> 37.3) and the plan stays one chain, whose launches are the ones the roofline figures describe.
-    s->chains = v.RS >= 1024 ? 2 : 1;
+    // two chains of launches (one per half of the replicas) in pedn_run; PEDN_STREAMS=1|2, pedn_set_streams.  Default from 640
+    // replicas: one chain's launch leaves wave places empty while it fills and drains, and the other half's launches use them
+    // (delft x 1024: 51.7 -> 45.3 us per step in round 2; round 5, melbourne / delft: x 640 25.8 -> 23.6 / 36.2 -> 34.3, x 768 27.1 -> 24.8,
+    // x 896 31.3 -> 27.5 / 45.3 -> 40.7; x 512 19.2 either way).  The halves are whole 128-replica segments (view_of): 640 = 384 + 256.
+    s->chains = v.RS >= 640 ? 2 : 1;
     if (const char* f = getenv("PEDN_STREAMS")) s->chains = atoi(f) == 2 ? 2 : 1;
     s->two_streams = s->chains > 1;
     // Owner-wave plan of pedn_run (launch_step: lazy): node_kernel<LU>(t + 1) performs the link update of t, one launch per step.  The
@@ -1358,13 +1358,15 @@ static void launch_link_update(pedn_sim* s, const DevView& v, hipStream_t stream
 }
 
 // this launch's share of the batch: the whole of it on the engine's stream (half = -1) or one half of the replicas per stream
-// (half = index of the chain, 0 .. run_chains - 1: chain c steps replicas [c, c + 1) * RS / run_chains on its own stream)
+// (half = index of the chain, 0 or 1: each steps its share of the replicas on its own stream)
 static DevView view_of(const pedn_sim* s, int half, hipStream_t* stream) {
   DevView v = s->v;
   *stream = s->stream;
   if (half >= 0) {
-    v.subRS = s->v.RS / s->run_chains;
-    v.sub0 = half * v.subRS;
+    // RS is a multiple of 128 (a wave of link_body covers 128 replicas): when the 128-replica segments do not halve, chain 0 takes one more
+    const int a = ((s->v.RS / 128 + 1) / 2) * 128;
+    v.sub0 = half ? a : 0;
+    v.subRS = half ? s->v.RS - a : a;
     *stream = chain_stream(s, half);
   }
   return v;
@@ -1555,7 +1557,7 @@ int pedn_profile_step(pedn_sim* s, int32_t t, float ms[3]) {
 // pedn_run's plan for the range [t0, t1): how many chains of launches (each a share of the replicas on its own stream)?
 static int chains_for(const pedn_sim* s, int t0, int t1) {
   if (s->chains < 2 || t1 - t0 < 8) return 1;
-  return s->v.RS % 256 == 0 ? 2 : 1;
+  return s->v.RS >= 256 ? 2 : 1;   // (every chain at least one 128-replica segment, view_of)
 }
 
 // Fork: every other chain's stream waits for what the engine's stream holds so far.

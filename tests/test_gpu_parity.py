@@ -509,12 +509,14 @@ def test_per_replica_widths_and_turning_fractions_via_replica_scope():
     net.close()
 
 
-@pytest.mark.parametrize("name,steps,hist", [("nine_intersections", 150, "full"), ("delft", 40, "full"), ("long_corridor", 150, "full"),
-                                             ("melbourne", 60, "full"), ("nine_intersections", 60, "recent"), ("delft", 40, "recent")])
+@pytest.mark.parametrize("name,steps,hist,reps", [("nine_intersections", 150, "full", 256), ("delft", 40, "full", 256), ("long_corridor", 150, "full", 256),
+                                                  ("melbourne", 60, "full", 256), ("nine_intersections", 60, "recent", 256), ("delft", 40, "recent", 256),
+                                                  # 128-replica segments that do not halve: the chains take 256 + 128 replicas
+                                                  ("delft", 40, "full", 384), ("melbourne", 60, "full", 320), ("nine_intersections", 60, "recent", 384)])
 @pytest.mark.parametrize("owner", ["0", "1"])
-def test_two_stream_plan_gives_identical_histories(name, steps, hist, owner, monkeypatch):
+def test_two_stream_plan_gives_identical_histories(name, steps, hist, reps, owner, monkeypatch):
     """pedn_run launches the two halves of a large batch as two chains on two streams (replicas are independent; the default
-    from 1024 replicas).  Same bits as the one-stream plan in every field and every replica, also when the run is cut into
+    from 768 replicas).  Same bits as the one-stream plan in every field and every replica, also when the run is cut into
     several calls, continues after a setter, and after a reset; turning fractions and error flags included."""
     from pednstream_amd import NetworkEnvGenerator
     from golden_util import DATA
@@ -523,7 +525,7 @@ def test_two_stream_plan_gives_identical_histories(name, steps, hist, owner, mon
         monkeypatch.setenv("PEDN_STREAMS", streams)
         monkeypatch.setenv("PEDN_LINK_OWNER", owner if streams == "2" else "0")   # the reference side: one chain, two launches per step
         np.random.seed(7)
-        net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=256, rng_seed=11, history=hist)
+        net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=reps, rng_seed=11, history=hist)
         e = net.engine()
         cut = steps // 3
         net.run(1, cut)                                   # two calls: the second one starts from fused turning fractions
@@ -537,8 +539,9 @@ def test_two_stream_plan_gives_identical_histories(name, steps, hist, owner, mon
             return e.read_block(LINK_FIELDS[f][0], min(first, last - 2), last)
 
         out = {f: held(f) for f in ALL_FIELDS}
-        out["tf"] = np.stack([np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 127, 128, 255)])
+        out["tf"] = np.stack([np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 127, 128, reps - 1)])
         out["flags"] = e.error_flags()[1]
+        assert e.plan_info()["chains"] == int(streams)
         e.reset()
         net.run(1, steps)
         out2 = {f: held(f) for f in ALL_FIELDS}
