@@ -2183,7 +2183,7 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
   const bool by_batch = s->v.RS >= 4096 || (s->v.pr && s->v.RS >= 1024);
   // on_device == 2: the caller chains this call between its own streams and pedn_stream() with events (no host synchronisation):
   // everything must then be ordered by the engine's stream alone
-  const bool two = on_device != 2 && (s->rl_chains == 2 || (s->rl_chains == 0 && by_batch)) && s->warmed_chains >= 2 && s->v.RS % 256 == 0 && s->fuse_obs && (!actions || (fold != nullptr && on_device)) &&
+  const bool two = on_device != 2 && (s->rl_chains == 2 || (s->rl_chains == 0 && by_batch)) && s->warmed_chains >= 2 && s->v.RS >= 256 && s->fuse_obs && (!actions || (fold != nullptr && on_device)) &&
                    s->link_pending < 0 && !(s->v.n_trow > 0 && !s->fuse_tp);
   if (!two) join_forked(s);
   else if (!s->forked) {

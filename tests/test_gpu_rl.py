@@ -175,15 +175,15 @@ def _step_device_check():
         e.close()
 
 
-@pytest.mark.parametrize("randomized", [False, True])
-def test_forked_rl_chains_give_the_same_episode(randomized, monkeypatch):
+@pytest.mark.parametrize("randomized,B", [(False, 256), (True, 256), (False, 384), (True, 320)])   # 384 / 320 envs: chains of 256 + 128
+def test_forked_rl_chains_give_the_same_episode(randomized, B, monkeypatch):
     """PEDN_RL_CHAINS=2: pedn_rl_step leaves the two halves of the envs stepping as two chains on two streams ACROSS calls and joins
     them only when something needs the whole batch.  Against one chain: device-resident actions stepped asynchronously in stretches,
     an observation fetch (join) after every stretch, a setter and host-side actions (which go through the engine's stream alone) in
     between, a reset and a second episode -- observations, rewards, histories, flags identical."""
     torch = pytest.importorskip("torch")
     g = Golden("rl_i45_opt3")
-    B, steps = 256, 48
+    steps = 48
 
     def episode(chains):
         monkeypatch.setenv("PEDN_RL_CHAINS", chains)
