@@ -509,6 +509,49 @@ def test_per_replica_widths_and_turning_fractions_via_replica_scope():
     net.close()
 
 
+@pytest.mark.parametrize("name,reps,hist", [("nine_intersections", 256, "full"), ("melbourne", 384, "full"), ("delft", 256, "recent")])
+def test_step_by_step_loop_keeps_the_chains_forked_across_calls(name, reps, hist, monkeypatch):
+    """The reference's calling sequence -- for t in range(1, T): network_loading(t) -- on a batch that steps as two chains: from the third
+    consecutive call the halves of the replicas step on two streams and stay forked ACROSS the calls (pedn_step); a read, a setter or a
+    reset in between joins them.  Same bits as one chain, call for call."""
+    from pednstream_amd import NetworkEnvGenerator
+    from golden_util import DATA
+
+    def history(streams):
+        monkeypatch.setenv("PEDN_STREAMS", streams)
+        monkeypatch.setenv("PEDN_STREAM_PROBE", "0")
+        np.random.seed(7)
+        net = NetworkEnvGenerator(DATA).create_network(name, verbose=False, n_replicas=reps, rng_seed=5, history=hist)
+        e = net.engine()
+        assert e.plan_info()["chains"] == int(streams)
+        out = []
+        steps = 45
+        for t in range(1, steps):
+            net.network_loading(t)
+            if t == 17:                                   # a read in the middle of the loop (joins the chains), then the loop goes on
+                out.append(e.read_block(LINK_FIELDS["cumulative_inflow"][0], t, t + 1))
+            if t == 29:                                   # a setter
+                link = next(iter(net.links.values()))
+                link.back_gate_width = 0.5 * link.width
+        first = 0 if hist == "full" else steps - 3
+        for f in ALL_FIELDS:
+            last = steps - 2 if hist == "recent" and f in ("sending_flow", "receiving_flow") else steps - 1
+            out.append(e.read_block(LINK_FIELDS[f][0], min(first, last - 1), last + 1))
+        out.append(np.stack([np.concatenate([e.get_turning_fractions(nd.index, r) for nd in net.nodes.values()]) for r in (0, 127, 128, reps - 1)]))
+        out.append(e.error_flags()[1])
+        e.reset()                                         # ... and a second episode, stepped the same way
+        for t in range(1, 12):
+            net.network_loading(t)
+        out.append(e.read_block(LINK_FIELDS["num_pedestrians"][0], 9, 12))
+        net.close()
+        return out
+
+    one, two = history("1"), history("2")
+    assert len(one) == len(two)
+    for k, (a, b) in enumerate(zip(one, two)):
+        assert np.array_equal(a, b), k
+
+
 @pytest.mark.parametrize("name,steps,hist,reps", [("nine_intersections", 150, "full", 256), ("delft", 40, "full", 256), ("long_corridor", 150, "full", 256),
                                                   ("melbourne", 60, "full", 256), ("nine_intersections", 60, "recent", 256), ("delft", 40, "recent", 256),
                                                   # 128-replica segments that do not halve: the chains take 256 + 128 replicas

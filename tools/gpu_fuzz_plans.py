@@ -24,14 +24,14 @@ for seed in range(lo, hi):
     if seed > lo and (seed - lo) % 100 == 0:
         print(f"#   ... seed {seed} of {lo}..{hi}: {ran} networks so far", flush=True)
     adj, params, origins, dests = random_case(seed)
-    R = 256 if seed % 4 == 0 else 3                      # every fourth network with a batch that steps as two chains
+    R = (384 if seed % 8 == 0 else 256) if seed % 4 == 0 else 3   # every fourth network with a batch that steps as two chains (384: 256 + 128)
     nets = []
     try:
         for plain in (False, True):
             keep = {k: os.environ.get(k) for k in PLAIN}
             if plain:
                 os.environ.update(PLAIN)
-            elif R == 256:
+            elif R >= 256:
                 os.environ["PEDN_STREAMS"] = "2"
                 os.environ["PEDN_STREAM_PROBE"] = "0"
             np.random.seed(seed)
@@ -84,7 +84,8 @@ for seed in range(lo, hi):
 
     stopped = False
     for op in range(int(rng.integers(8, 22))):
-        kind = rng.choice(["run", "step", "repeat", "read", "width", "tf", "demand", "reset", "compare"], p=[0.3, 0.2, 0.04, 0.1, 0.08, 0.06, 0.06, 0.08, 0.08])
+        kind = rng.choice(["run", "step", "steps", "repeat", "read", "width", "tf", "demand", "reset", "compare"],
+                          p=[0.22, 0.14, 0.14, 0.04, 0.1, 0.08, 0.06, 0.06, 0.08, 0.08])
         ops_total += 1
         log.append((str(kind), t))
         if kind == "run" and t < T:
@@ -96,6 +97,12 @@ for seed in range(lo, hi):
             for net in nets:
                 net.network_loading(t)
             t += 1
+        elif kind == "steps" and t < T:   # the reference's loop: call after call (from the third one on the chains stay forked across the calls)
+            n = min(int(rng.integers(3, 14)), T - t)
+            for net in nets:
+                for k in range(n):
+                    net.network_loading(t + k)
+            t += n
         elif kind == "repeat" and t > 3 and not recent:
             for net in nets:
                 net.engine().step(t - 1)
@@ -141,6 +148,6 @@ for seed in range(lo, hi):
     for net in nets:
         net.close()
     ran += 1
-print(f"the engine's own launch plans == two launches per step on one stream: {ran} random networks (3 or 256 replicas, every fifth in recent-history mode), "
+print(f"the engine's own launch plans == two launches per step on one stream: {ran} random networks (3, 256 or 384 replicas, every fifth in recent-history mode), "
       f"{ops_total} random calls; plans of engine A (chains, link update by the next node kernel): {plans}; every field, turning fraction and flag identical "
       f"whenever compared; {n_flagged} scenarios stopped at a zero look-back, {skipped} networks skipped")
