@@ -114,6 +114,8 @@ struct pedn_sim {
   struct Stage { void* pin = nullptr; void* dev = nullptr; size_t bytes = 0; hipEvent_t done = nullptr; };
   Stage stage[2];
   int stage_next = 0;
+  void* rl_pin = nullptr;      // pinned landing buffer of the RL step's observations + rewards (rl_fetch)
+  size_t rl_pin_bytes = 0;
   std::string err;
 };
 
@@ -182,6 +184,22 @@ static int stage_upload(pedn_sim* s, pedn_sim::Stage* st, const void* src, size_
 static int stage_commit(pedn_sim* s, pedn_sim::Stage* st) {
   HIP_TRY(s, hipEventRecord(st->done, s->stream));
   return PEDN_OK;
+}
+
+// host bytes -> a device buffer of the engine.  Up to 16 KB through a pinned slot: the caller's memory is not touched after the return
+// and the call does not wait for the stream (a copy from pageable memory does both: 7-25 us per call of a host-driven env step)
+static int upload_through_stage(pedn_sim* s, void* dst, const void* src, size_t bytes) {
+  if (bytes > 16384) {   // larger rows: the plain copy (which waits) measured no slower with a fetch behind it and faster without one
+    HIP_TRY(s, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream));   // (tools/host_step_time.py, 1024 .. 4096 envs x 4 actions)
+    HIP_TRY(s, hipStreamSynchronize(s->stream));  // the host buffer is borrowed for the call only
+    return PEDN_OK;
+  }
+  pedn_sim::Stage* st;
+  int rc = stage_acquire(s, bytes, &st);
+  if (rc != PEDN_OK) return rc;
+  memcpy(st->pin, src, bytes);
+  HIP_TRY(s, hipMemcpyAsync(dst, st->pin, bytes, hipMemcpyHostToDevice, s->stream));
+  return stage_commit(s, st);
 }
 
 // The first launch on a stream and the first cross-stream wait cost the runtime ~0.2 ms (queue creation, signal set-up): pay
@@ -1023,6 +1041,7 @@ int pedn_destroy(pedn_sim* s) {
   if (s->stream2) hipStreamSynchronize(s->stream2);
   if (s->stream) hipStreamSynchronize(s->stream);
   for (void* p : s->allocs) hipFree(p);
+  if (s->rl_pin) hipHostFree(s->rl_pin);
   for (pedn_sim::Stage& st : s->stage) {
     if (st.dev) hipFree(st.dev);
     if (st.pin) hipHostFree(st.pin);
@@ -2138,11 +2157,35 @@ int pedn_rl_apply_actions(pedn_sim* s, const double* actions, int32_t on_device)
   const size_t bytes = (size_t)v.R * q.A * sizeof(double);
   RlView qq = q;
   if (on_device) qq.actions = const_cast<double*>(actions);  // read the caller's rows in place: no staging copy
-  else HIP_TRY(s, hipMemcpyAsync(q.actions, actions, bytes, hipMemcpyHostToDevice, s->stream));
+  else {   // the host buffer is borrowed for the call only: through a pinned slot, without waiting for the stream
+    const int rc = upload_through_stage(s, q.actions, actions, bytes);
+    if (rc != PEDN_OK) return rc;
+  }
   size_t n = (size_t)q.A * v.RS;
   hipLaunchKernelGGL(rl_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, qq);
   HIP_TRY(s, hipGetLastError());
-  if (!on_device) HIP_TRY(s, hipStreamSynchronize(s->stream));  // the host buffer is borrowed for the call only
+  return PEDN_OK;
+}
+
+// observations / rewards -> the caller's buffers: both copies land in ONE pinned buffer, one wait for the stream, then two memcpys (into
+// pageable memory each copy is staged and waited for by the runtime on its own)
+static int rl_fetch(pedn_sim* s, float* obs, float* rewards) {
+  if (!obs && !rewards) return PEDN_OK;
+  const RlView& q = s->rl;
+  const size_t nb_obs = (size_t)s->v.R * q.O * sizeof(float), nb_rew = (size_t)s->v.R * q.n_agents * sizeof(float);
+  if (s->rl_pin_bytes < nb_obs + nb_rew) {
+    if (s->rl_pin) HIP_TRY(s, hipHostFree(s->rl_pin));
+    s->rl_pin = nullptr;
+    s->rl_pin_bytes = 0;
+    HIP_TRY(s, hipHostMalloc(&s->rl_pin, nb_obs + nb_rew, hipHostMallocDefault));
+    s->rl_pin_bytes = nb_obs + nb_rew;
+  }
+  char* pin = (char*)s->rl_pin;
+  if (obs) HIP_TRY(s, hipMemcpyAsync(pin, q.obs, nb_obs, hipMemcpyDeviceToHost, s->stream));
+  if (rewards) HIP_TRY(s, hipMemcpyAsync(pin + nb_obs, q.rew, nb_rew, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  if (obs) memcpy(obs, pin, nb_obs);
+  if (rewards) memcpy(rewards, pin + nb_obs, nb_rew);
   return PEDN_OK;
 }
 
@@ -2158,10 +2201,7 @@ int pedn_rl_observe(pedn_sim* s, int32_t t, int32_t accumulate, float* obs, floa
   if (v.hist) hipLaunchKernelGGL(rl_observe_kernel<true>, dim3((unsigned)q.n_agents * (unsigned)(v.RS / 64)), dim3(256), 0, s->stream, v, q, t, accumulate);
   else hipLaunchKernelGGL(rl_observe_kernel<false>, dim3((unsigned)q.n_agents * (unsigned)(v.RS / 64)), dim3(256), 0, s->stream, v, q, t, accumulate);
   HIP_TRY(s, hipGetLastError());
-  if (obs) HIP_TRY(s, hipMemcpyAsync(obs, q.obs, (size_t)v.R * q.O * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-  if (rewards) HIP_TRY(s, hipMemcpyAsync(rewards, q.rew, (size_t)v.R * q.n_agents * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-  if (obs || rewards) HIP_TRY(s, hipStreamSynchronize(s->stream));
-  return PEDN_OK;
+  return rl_fetch(s, obs, rewards);
 }
 
 int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t t, int32_t action_gap, float* obs, float* rewards) {
@@ -2184,8 +2224,7 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
       HIP_TRY(s, hipSetDevice(s->device));
       if (on_device) fold = actions;
       else {
-        HIP_TRY(s, hipMemcpyAsync(q.actions, actions, (size_t)s->v.R * q.A * sizeof(double), hipMemcpyHostToDevice, s->stream));
-        HIP_TRY(s, hipStreamSynchronize(s->stream));  // the host buffer is borrowed for the call only
+        if ((rc = upload_through_stage(s, q.actions, actions, (size_t)s->v.R * q.A * sizeof(double))) != PEDN_OK) return rc;
         fold = q.actions;
       }
     } else if ((rc = pedn_rl_apply_actions(s, actions, on_device)) != PEDN_OK) return rc;   // (performs a pending link update first)
@@ -2226,9 +2265,7 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
     if (!observed) {
       if ((rc = pedn_rl_observe(s, t + k, k > 0, last ? obs : nullptr, last ? rewards : nullptr)) != PEDN_OK) return rc;
     } else if (last && (obs || rewards)) {
-      if (obs) HIP_TRY(s, hipMemcpyAsync(obs, q.obs, (size_t)s->v.R * q.O * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-      if (rewards) HIP_TRY(s, hipMemcpyAsync(rewards, q.rew, (size_t)s->v.R * q.n_agents * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-      HIP_TRY(s, hipStreamSynchronize(s->stream));
+      if ((rc = rl_fetch(s, obs, rewards)) != PEDN_OK) return rc;
     }
   }
   return PEDN_OK;
