@@ -331,6 +331,11 @@ int pedn_rl_apply_actions(pedn_sim* sim, const double* actions, int32_t on_devic
  * the buffer (float32, like the reference's cumulative_rewards) instead of overwriting.  obs / rewards may be NULL;
  * otherwise they receive host copies [n_replicas][n_obs] / [n_replicas][n_agents] (synchronises). */
 int pedn_rl_observe(pedn_sim* sim, int32_t t, int32_t accumulate, float* obs, float* rewards);
+/* The observation / reward buffers as the last pedn_rl_step / pedn_rl_observe left them -> host (either pointer may be NULL); waits
+ * for the engine's work.  For callers that step SEVERAL engines before they look at any of them: pedn_rl_step(..., NULL, NULL) on every
+ * engine, then one fetch each -- the engines' launches overlap instead of alternating with host waits (MultiScenarioVecEnv: one engine
+ * per randomised topology, rl/pz_pednet_env.py:143-193 rebuilds the network per reset). */
+int pedn_rl_fetch(pedn_sim* sim, float* obs, float* rewards);
 /* apply -> action_gap x (pedn_step(t+k), observe) in one call (pz_pednet_env.py:195-254).  obs / rewards NULL: asynchronous, the
  * results stay in the device buffers (pedn_rl_device_ptr), complete after pedn_synchronize.  With on_device actions and nothing
  * fetched, large batches step as two chains on two streams that stay forked across calls (the halves of the envs are independent);

@@ -2204,6 +2204,14 @@ int pedn_rl_observe(pedn_sim* s, int32_t t, int32_t accumulate, float* obs, floa
   return rl_fetch(s, obs, rewards);
 }
 
+int pedn_rl_fetch(pedn_sim* s, float* obs, float* rewards) {
+  if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
+  if (!s->rl_ready) return fail(s, PEDN_E_ARG, "pedn_rl_configure has not been called");
+  HIP_TRY(s, hipSetDevice(s->device));
+  join_forked(s);   // (ends a clocked section; both chains' work in front of the copies)
+  return rl_fetch(s, obs, rewards);
+}
+
 int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t t, int32_t action_gap, float* obs, float* rewards) {
   if (!s) return fail(nullptr, PEDN_E_ARG, "null handle");
   if (action_gap < 1 || t < 1 || t + action_gap - 1 > s->v.T1 - 1) return fail(s, PEDN_E_ARG, "step range outside 1..T");

@@ -167,6 +167,7 @@ def _load():
         "pedn_rl_configure": (C.c_int, [P, C.POINTER(RlDesc), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "pedn_rl_apply_actions": (C.c_int, [P, C.c_void_p, C.c_int32]),
         "pedn_rl_observe": (C.c_int, [P, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+        "pedn_rl_fetch": (C.c_int, [P, C.c_void_p, C.c_void_p]),
         "pedn_rl_step": (C.c_int, [P, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
         "pedn_rl_device_ptr": (C.c_void_p, [P, C.c_int32]),
         "pedn_rl_clock_begin": (C.c_int, [P, C.c_int32]),
@@ -202,7 +203,7 @@ EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
            "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_reset_lazy", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_plan_info", "pedn_rl_configure",
-           "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
+           "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_fetch", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
            "pedn_set_od_weights_per_replica", "pedn_get_od_weights_per_replica", "pedn_get_link_params", "pedn_randomize_scenarios", "pedn_reset_widths",
            "pedn_flush", "pedn_rl_clock_begin", "pedn_rl_step_clocked", "pedn_rl_clock_end", "pedn_rl_clocked", "pedn_rl_clock_signature"]
 
@@ -479,6 +480,13 @@ class Engine:
         obs = np.empty((self.n_replicas, self.rl_n_obs), dtype=np.float32)
         rew = np.empty((self.n_replicas, self.rl_n_agents), dtype=np.float32)
         self._ck(self._lib.pedn_rl_observe(self._h, int(t), int(accumulate), obs.ctypes.data_as(C.c_void_p), rew.ctypes.data_as(C.c_void_p)))
+        return obs, rew
+
+    def rl_fetch(self):
+        """Host copies of the observation / reward buffers as the last rl_step / rl_observe left them (pedn_rl_fetch)."""
+        obs = np.empty((self.n_replicas, self.rl_n_obs), dtype=np.float32)
+        rew = np.empty((self.n_replicas, self.rl_n_agents), dtype=np.float32)
+        self._ck(self._lib.pedn_rl_fetch(self._h, obs.ctypes.data_as(C.c_void_p), rew.ctypes.data_as(C.c_void_p)))
         return obs, rew
 
     def rl_step(self, actions, t, action_gap=1, fetch=True, ordered=False):

@@ -267,6 +267,20 @@ class VecPedNetEnv:
         terminated = (self.sim_step - 1) >= self.simulation_steps     # pz_pednet_env.py:592 evaluated before the increment
         return obs, rew, terminated, False, {}
 
+    def step_async(self, actions):
+        """``step`` in two halves for a caller that steps several batched envs before it looks at any of them (``MultiScenarioVecEnv``):
+        the launches are enqueued, nothing is waited for; ``step_wait`` fetches."""
+        if self.sim_step + self.action_gap - 1 > self.simulation_steps:
+            raise IndexError("episode is over; call reset()")
+        self.network._flush().rl_step(actions, self.sim_step, self.action_gap, fetch=False)
+        self.sim_step += self.action_gap
+        self.network.current_step = self.sim_step - 1
+        self.network._widths_stale = True
+
+    def step_wait(self):
+        obs, rew = self.network.engine().rl_fetch()
+        return obs, rew, (self.sim_step - 1) >= self.simulation_steps, False, {}
+
     def step_device(self, actions, sync=True):
         """``step`` for an on-GPU learner: ``actions`` is a torch CUDA tensor (float64, [n_envs, n_actions], contiguous) or None;
         returns ``(obs, rewards, terminated)`` where obs [n_envs, n_obs] and rewards [n_envs, n_agents] are float32 torch tensors
@@ -639,10 +653,11 @@ class MultiScenarioVecEnv:
 
     def step(self, actions):
         actions = np.asarray(actions, dtype=np.float64)
-        outs, off = [], 0
-        for g, size in zip(self.groups, self.sizes):
-            outs.append(g.step(actions[off:off + size]))
-            off += size
+        offs = np.concatenate([[0], np.cumsum(self.sizes)])
+        jobs = [(g, actions[offs[k]:offs[k + 1]]) for k, g in enumerate(self.groups)]
+        for g, a in jobs:                                   # every group's launches first (own engine, own stream: they overlap) ...
+            g.step_async(a)
+        outs = [g.step_wait() for g in self.groups]         # ... then one fetch each.  (Issued from 2-16 host threads instead: slower.)
         return (np.concatenate([o[0] for o in outs], axis=0), np.concatenate([o[1] for o in outs], axis=0), outs[0][2], False, {})
 
     def close(self):

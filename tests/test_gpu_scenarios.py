@@ -251,6 +251,12 @@ def test_multi_scenario_env_groups_have_their_own_topology():
     for _ in range(steps):         # t = 1..steps: sending/receiving flows are then defined up to index steps-1
         obs, rew, term, trunc, _ = env.step(np.tile(env.action_high, (5, 1)))      # gates fully open = unchanged widths
     assert obs.shape == (5, env.n_obs) and np.isfinite(obs).all()
+    # the groups' launches are enqueued first and fetched afterwards (step_async / step_wait): every group's rows are its own
+    off = 0
+    for grp in env.groups:
+        o, r = grp.network.engine().rl_observe(grp.sim_step - 1, accumulate=False)
+        assert np.array_equal(obs[off:off + grp.n_envs], o) and np.array_equal(rew[off:off + grp.n_envs], r)
+        off += grp.n_envs
     e = nets[0]._engine
     problems = compare_fields(lambda nm: e.read_block(LINK_FIELDS[nm][0], 0, steps, rep0=0, rep1=1)[:, :, 0].T, g, e.n_links, steps)
     assert not problems, "\n".join(problems)
