@@ -154,6 +154,7 @@ static int dalloc(pedn_sim* s, size_t n, T** dst) {
 }
 
 // A staging slot of at least `bytes` whose previous use has completed (the other slot may still be in flight).
+#define PEDN_IN_PLACE_BYTES 16384
 static int stage_acquire(pedn_sim* s, size_t bytes, pedn_sim::Stage** out) {
   pedn_sim::Stage& st = s->stage[s->stage_next];
   s->stage_next ^= 1;
@@ -183,6 +184,16 @@ static int stage_upload(pedn_sim* s, pedn_sim::Stage* st, const void* src, size_
 // call after the last launch that reads or writes the slot
 static int stage_commit(pedn_sim* s, pedn_sim::Stage* st) {
   HIP_TRY(s, hipEventRecord(st->done, s->stream));
+  return PEDN_OK;
+}
+
+// Small host rows that ONE kernel reads once (the action rows of a host-driven env step): copied into a pinned slot and read by the
+// kernel IN PLACE over the bus -- no copy command in front of the launch (2 KB of actions: a DMA of ~20 us of stream latency against
+// one bus read inside the consuming wave).  The caller records the slot's event behind the consuming launch (stage_commit).
+static int stage_in_place(pedn_sim* s, const void* src, size_t bytes, pedn_sim::Stage** out) {
+  int rc = stage_acquire(s, bytes, out);
+  if (rc != PEDN_OK) return rc;
+  memcpy((*out)->pin, src, bytes);
   return PEDN_OK;
 }
 
@@ -2098,8 +2109,9 @@ int pedn_rl_configure(pedn_sim* s, const pedn_rl_desc* d, int32_t* n_actions, in
   UP(slot_idx.data(), slot_idx.size(), &q.slot_idx);
 #undef UP
   if ((rc = dalloc(s, (size_t)v.R * A, &q.actions)) != PEDN_OK) return rc;
-  if ((rc = dalloc(s, (size_t)v.R * O, &q.obs)) != PEDN_OK) return rc;
-  if ((rc = dalloc(s, (size_t)v.R * d->n_agents, &q.rew)) != PEDN_OK) return rc;
+  // observations and rewards in ONE allocation, rewards right behind the observations: a fetch of both is one copy (rl_fetch)
+  if ((rc = dalloc(s, (size_t)v.R * O + (size_t)v.R * d->n_agents, &q.obs)) != PEDN_OK) return rc;
+  q.rew = q.obs + (size_t)v.R * O;
   HIP_TRY(s, hipMemset(q.obs, 0, (size_t)v.R * O * sizeof(float)));
   HIP_TRY(s, hipMemset(q.rew, 0, (size_t)v.R * d->n_agents * sizeof(float)));
   q.n_agents = d->n_agents; q.A = A; q.O = O; q.obs_mode = d->obs_mode; q.normalize = d->normalize; q.reward_mode = d->reward_mode;
@@ -2157,13 +2169,18 @@ int pedn_rl_apply_actions(pedn_sim* s, const double* actions, int32_t on_device)
   const size_t bytes = (size_t)v.R * q.A * sizeof(double);
   RlView qq = q;
   if (on_device) qq.actions = const_cast<double*>(actions);  // read the caller's rows in place: no staging copy
-  else {   // the host buffer is borrowed for the call only: through a pinned slot, without waiting for the stream
-    const int rc = upload_through_stage(s, q.actions, actions, bytes);
-    if (rc != PEDN_OK) return rc;
+  pedn_sim::Stage* st = nullptr;
+  if (!on_device) {   // the host buffer is borrowed for the call only
+    int rc;
+    if (bytes <= PEDN_IN_PLACE_BYTES) {
+      if ((rc = stage_in_place(s, actions, bytes, &st)) != PEDN_OK) return rc;
+      qq.actions = (double*)st->pin;
+    } else if ((rc = upload_through_stage(s, q.actions, actions, bytes)) != PEDN_OK) return rc;
   }
   size_t n = (size_t)q.A * v.RS;
   hipLaunchKernelGGL(rl_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, v, qq);
   HIP_TRY(s, hipGetLastError());
+  if (st) return stage_commit(s, st);
   return PEDN_OK;
 }
 
@@ -2181,8 +2198,9 @@ static int rl_fetch(pedn_sim* s, float* obs, float* rewards) {
     s->rl_pin_bytes = nb_obs + nb_rew;
   }
   char* pin = (char*)s->rl_pin;
-  if (obs) HIP_TRY(s, hipMemcpyAsync(pin, q.obs, nb_obs, hipMemcpyDeviceToHost, s->stream));
-  if (rewards) HIP_TRY(s, hipMemcpyAsync(pin + nb_obs, q.rew, nb_rew, hipMemcpyDeviceToHost, s->stream));
+  if (obs && rewards) HIP_TRY(s, hipMemcpyAsync(pin, q.obs, nb_obs + nb_rew, hipMemcpyDeviceToHost, s->stream));   // (contiguous: pedn_rl_configure)
+  else if (obs) HIP_TRY(s, hipMemcpyAsync(pin, q.obs, nb_obs, hipMemcpyDeviceToHost, s->stream));
+  else HIP_TRY(s, hipMemcpyAsync(pin + nb_obs, q.rew, nb_rew, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   if (obs) memcpy(obs, pin, nb_obs);
   if (rewards) memcpy(rewards, pin + nb_obs, nb_rew);
@@ -2226,14 +2244,21 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
   // fractions of step t still have to be computed by their own launch in front of node_kernel: their capacity fallback reads
   // the gate widths the actions are about to change (path_finder.py:575-576).
   const double* fold = nullptr;
+  pedn_sim::Stage* fold_stage = nullptr;   // host actions read in place by node_kernel of the first sub-step (stage_in_place)
   if (actions) {
     const bool stand_alone_tf = s->v.n_trow > 0 && s->tp_ready != t;
     if (s->rl_fold && !stand_alone_tf) {
       HIP_TRY(s, hipSetDevice(s->device));
       if (on_device) fold = actions;
       else {
-        if ((rc = upload_through_stage(s, q.actions, actions, (size_t)s->v.R * q.A * sizeof(double))) != PEDN_OK) return rc;
-        fold = q.actions;
+        const size_t bytes = (size_t)s->v.R * q.A * sizeof(double);
+        if (bytes <= PEDN_IN_PLACE_BYTES) {
+          if ((rc = stage_in_place(s, actions, bytes, &fold_stage)) != PEDN_OK) return rc;
+          fold = (const double*)fold_stage->pin;
+        } else {
+          if ((rc = upload_through_stage(s, q.actions, actions, bytes)) != PEDN_OK) return rc;
+          fold = q.actions;
+        }
       }
     } else if ((rc = pedn_rl_apply_actions(s, actions, on_device)) != PEDN_OK) return rc;   // (performs a pending link update first)
   }
@@ -2269,6 +2294,7 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
       if ((last && (obs || rewards)) || !observed) join_forked(s);
     } else
       if ((rc = launch_step(s, t + k, nullptr, k > 0 ? 1 : 0, &observed, k == 0 ? fold : nullptr, -1, false)) != PEDN_OK) return rc;
+      if (k == 0 && fold_stage && (rc = stage_commit(s, fold_stage)) != PEDN_OK) return rc;   // its only reader has been launched
     HIP_TRY(s, hipGetLastError());
     if (!observed) {
       if ((rc = pedn_rl_observe(s, t + k, k > 0, last ? obs : nullptr, last ? rewards : nullptr)) != PEDN_OK) return rc;
