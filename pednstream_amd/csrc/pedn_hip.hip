@@ -154,7 +154,7 @@ static int dalloc(pedn_sim* s, size_t n, T** dst) {
 }
 
 // A staging slot of at least `bytes` whose previous use has completed (the other slot may still be in flight).
-#define PEDN_IN_PLACE_BYTES 16384
+#define PEDN_IN_PLACE_BYTES (4u << 20)   // host rows up to this size are read in place by their consuming kernel (stage_in_place; measured up to 256 KB)
 static int stage_acquire(pedn_sim* s, size_t bytes, pedn_sim::Stage** out) {
   pedn_sim::Stage& st = s->stage[s->stage_next];
   s->stage_next ^= 1;
@@ -187,9 +187,10 @@ static int stage_commit(pedn_sim* s, pedn_sim::Stage* st) {
   return PEDN_OK;
 }
 
-// Small host rows that ONE kernel reads once (the action rows of a host-driven env step): copied into a pinned slot and read by the
-// kernel IN PLACE over the bus -- no copy command in front of the launch (2 KB of actions: a DMA of ~20 us of stream latency against
-// one bus read inside the consuming wave).  The caller records the slot's event behind the consuming launch (stage_commit).
+// Host rows that ONE kernel reads once (the action rows of a host-driven env step): copied into a pinned slot and read by the kernel IN
+// PLACE over the bus -- no copy command in front of the launch (a DMA costs ~20 us of stream latency, a copy from pageable memory waits
+// for the stream; the consuming wave's bus read costs it ~2 us).  The caller records the slot's event behind the consuming launch
+// (stage_commit).  2048 envs: 93-96 -> 81 us per host-driven step, 48 -> 29 without a fetch.
 static int stage_in_place(pedn_sim* s, const void* src, size_t bytes, pedn_sim::Stage** out) {
   int rc = stage_acquire(s, bytes, out);
   if (rc != PEDN_OK) return rc;
@@ -197,20 +198,13 @@ static int stage_in_place(pedn_sim* s, const void* src, size_t bytes, pedn_sim::
   return PEDN_OK;
 }
 
-// host bytes -> a device buffer of the engine.  Up to 16 KB through a pinned slot: the caller's memory is not touched after the return
-// and the call does not wait for the stream (a copy from pageable memory does both: 7-25 us per call of a host-driven env step)
+// host bytes -> a device buffer of the engine; the caller's memory is borrowed for the call only, so the copy is waited for (rows beyond
+// PEDN_IN_PLACE_BYTES; what was measured instead for smaller ones -- a copy COMMAND from a pinned slot, a copy KERNEL from it -- lost to
+// reading them in place, profiles/r05_host_step_time.txt)
 static int upload_through_stage(pedn_sim* s, void* dst, const void* src, size_t bytes) {
-  if (bytes > 16384) {   // larger rows: the plain copy (which waits) measured no slower with a fetch behind it and faster without one
-    HIP_TRY(s, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream));   // (tools/host_step_time.py, 1024 .. 4096 envs x 4 actions)
-    HIP_TRY(s, hipStreamSynchronize(s->stream));  // the host buffer is borrowed for the call only
-    return PEDN_OK;
-  }
-  pedn_sim::Stage* st;
-  int rc = stage_acquire(s, bytes, &st);
-  if (rc != PEDN_OK) return rc;
-  memcpy(st->pin, src, bytes);
-  HIP_TRY(s, hipMemcpyAsync(dst, st->pin, bytes, hipMemcpyHostToDevice, s->stream));
-  return stage_commit(s, st);
+  HIP_TRY(s, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  return PEDN_OK;
 }
 
 // The first launch on a stream and the first cross-stream wait cost the runtime ~0.2 ms (queue creation, signal set-up): pay
@@ -2275,7 +2269,7 @@ int pedn_rl_step(pedn_sim* s, const double* actions, int32_t on_device, int32_t 
   const bool by_batch = s->v.RS >= 4096 || (s->v.pr && s->v.RS >= 1024);
   // on_device == 2: the caller chains this call between its own streams and pedn_stream() with events (no host synchronisation):
   // everything must then be ordered by the engine's stream alone
-  const bool two = on_device != 2 && (s->rl_chains == 2 || (s->rl_chains == 0 && by_batch)) && s->warmed_chains >= 2 && s->v.RS >= 256 && s->fuse_obs && (!actions || (fold != nullptr && on_device)) &&
+  const bool two = on_device != 2 && (s->rl_chains == 2 || (s->rl_chains == 0 && by_batch)) && s->warmed_chains >= 2 && s->v.RS >= 256 && s->fuse_obs && (!actions || (fold != nullptr && on_device)) && !obs && !rewards &&
                    s->link_pending < 0 && !(s->v.n_trow > 0 && !s->fuse_tp);
   if (!two) join_forked(s);
   else if (!s->forked) {
