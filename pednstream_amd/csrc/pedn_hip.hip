@@ -154,6 +154,7 @@ static int dalloc(pedn_sim* s, size_t n, T** dst) {
 }
 
 // A staging slot of at least `bytes` whose previous use has completed (the other slot may still be in flight).
+#define PEDN_DIRECT_READ_BYTES 65536     // pedn_read_block: up to this size the gather kernel writes into the pinned buffer itself
 #define PEDN_IN_PLACE_BYTES (4u << 20)   // host rows up to this size are read in place by their consuming kernel (stage_in_place; measured up to 256 KB)
 static int stage_acquire(pedn_sim* s, size_t bytes, pedn_sim::Stage** out) {
   pedn_sim::Stage& st = s->stage[s->stage_next];
@@ -1825,7 +1826,7 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
   }
   HIP_TRY(s, hipSetDevice(s->device));
   pending_links_first(s);
-  HIP_TRY(s, hipStreamSynchronize(s->stream));
+  // (no wait here: everything the gather reads was written by earlier work on this stream)
   size_t n = (size_t)(t1 - t0) * (c1 - c0) * (r1 - r0);
   size_t esz = field < 7 ? 8 : 4;
   pedn_sim::Stage* st;
@@ -1841,14 +1842,18 @@ int pedn_read(pedn_sim* s, int32_t field, int32_t t0, int32_t t1, int32_t c0, in
     else if (field == F_GATE) hi = 0x7fffffff;
     else if (field == 7 + G_ATT) hi = std::max(hi, v.W - 1);
   }
+  // small reads (a controller looking at a few values after every step): the gather writes STRAIGHT into the pinned buffer over the bus --
+  // no copy command behind the kernel (its ~10 us of stream latency were half of such a read)
+  const bool direct = n * esz <= PEDN_DIRECT_READ_BYTES;
+  void* const dst = direct ? st->pin : st->dev;
   if (field < 7)
-    hipLaunchKernelGGL(gather_kernel<double>, dim3(blocks), dim3(256), 0, s->stream, (const double*)v.f64[field], (double*)st->dev, t0,
+    hipLaunchKernelGGL(gather_kernel<double>, dim3(blocks), dim3(256), 0, s->stream, (const double*)v.f64[field], (double*)dst, t0,
                        t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS, mask, hi, (field == F_S || field == F_R) ? -1.0 : 0.0);
   else
-    hipLaunchKernelGGL(gather_kernel<float>, dim3(blocks), dim3(256), 0, s->stream, (const float*)v.f32[field - 7], (float*)st->dev, t0,
+    hipLaunchKernelGGL(gather_kernel<float>, dim3(blocks), dim3(256), 0, s->stream, (const float*)v.f32[field - 7], (float*)dst, t0,
                        t1 - t0, c0, c1 - c0, r0, r1 - r0, cols, v.RS, mask, hi, 0.0f);
   HIP_TRY(s, hipGetLastError());
-  HIP_TRY(s, hipMemcpyAsync(st->pin, st->dev, n * esz, hipMemcpyDeviceToHost, s->stream));
+  if (!direct) HIP_TRY(s, hipMemcpyAsync(st->pin, st->dev, n * esz, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(s, hipStreamSynchronize(s->stream));
   memcpy(out, st->pin, n * esz);
   return stage_commit(s, st);
