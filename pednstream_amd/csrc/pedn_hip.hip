@@ -1275,10 +1275,21 @@ int pedn_set_width(pedn_sim* s, int32_t which, int32_t link, int32_t replica, do
   HIP_TRY(s, hipSetDevice(s->device));
   pending_links_first(s);     // the link update records the gate / reads the separator width of its own step
   if (which == PEDN_W_BACK) s->tp_ready = -1;  // capacity fallback of the turn probabilities (path_finder.py:575-576)
-  int rc = push_rows(s, dst, &value, 1, (size_t)link, 1, replica);
-  if (rc != PEDN_OK || which > PEDN_W_BACK) return rc;
-  (which == PEDN_W_FRONT ? s->h_front_u : s->h_back_u)[link] = replica == PEDN_ALL ? value : __builtin_nan("");
-  return push_uniform(s);
+  join_forked(s);   // (as every setter: ordered behind both chains)
+  // one launch, its values as kernel arguments: the row's replicas and the link's entry of the replica-uniform shortcut (front_u / back_u:
+  // NaN = "differs between replicas"; a link the RL agents write per replica keeps NaN, push_uniform)
+  double* uni = nullptr;
+  double uval = 0.0;
+  if (which <= PEDN_W_BACK) {
+    std::vector<double>& hu = which == PEDN_W_FRONT ? s->h_front_u : s->h_back_u;
+    hu[link] = replica == PEDN_ALL ? value : __builtin_nan("");
+    uval = (link < (int)s->h_rl_link.size() && s->h_rl_link[link]) ? __builtin_nan("") : hu[link];
+    uni = (which == PEDN_W_FRONT ? s->d_front_u : s->d_back_u) + link;
+  }
+  const int r0 = replica == PEDN_ALL ? 0 : replica, n = replica == PEDN_ALL ? s->v.RS : 1;
+  hipLaunchKernelGGL(set_width_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, dst + (size_t)link * s->v.RS, r0, n, value, uni, uval);
+  HIP_TRY(s, hipGetLastError());
+  return PEDN_OK;
 }
 
 int pedn_set_widths(pedn_sim* s, int32_t which, const double* values) {

@@ -1752,6 +1752,15 @@ __global__ void rand_demand_kernel(double* dst, const int32_t* rows, const int32
   dst[(row * T1 + t) * RS + r] = val;
 }
 
+// pedn_set_width: ONE value into the replicas [r0, r0 + n) of one link's width row, and the link's replica-uniform shortcut entry beside it
+// -- the values travel as kernel arguments: no staging copy, no host memory that has to outlive the call, nothing to wait for (a host-side
+// controller sets a width after every step)
+__global__ void set_width_kernel(double* row, int r0, int n, double value, double* uniform_entry, double uniform_value) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n) row[r0 + i] = value;
+  if (i == 0 && uniform_entry != nullptr) *uniform_entry = uniform_value;
+}
+
 // pedn_rl_clock_begin: the device clock (node_clock) set to step t
 __global__ void set_clock_kernel(int32_t* clock, int t, int valid_hi) {
   if (threadIdx.x == 0) { clock[0] = t; clock[1] = t; clock[2] = valid_hi; clock[3] = 0; }
