@@ -336,6 +336,10 @@ int pedn_rl_observe(pedn_sim* sim, int32_t t, int32_t accumulate, float* obs, fl
  * engine, then one fetch each -- the engines' launches overlap instead of alternating with host waits (MultiScenarioVecEnv: one engine
  * per randomised topology, rl/pz_pednet_env.py:143-193 rebuilds the network per reset). */
 int pedn_rl_fetch(pedn_sim* sim, float* obs, float* rewards);
+/* pedn_rl_step(.., NULL, NULL) on every engine of sims[0 .. n), then pedn_rl_fetch of each, in ONE call: the engines' launches overlap and
+ * the per-engine cost of a host-side loop over handles is gone (MultiScenarioVecEnv: 32 engines x 64 envs).  actions / obs / rewards are the
+ * engines' rows one after the other (engine k: its n_replicas rows); all engines step the same t with the same agent layout. */
+int pedn_rl_step_many(pedn_sim** sims, int32_t n, const double* actions, int32_t t, int32_t action_gap, float* obs, float* rewards);
 /* apply -> action_gap x (pedn_step(t+k), observe) in one call (pz_pednet_env.py:195-254).  obs / rewards NULL: asynchronous, the
  * results stay in the device buffers (pedn_rl_device_ptr), complete after pedn_synchronize.  With on_device actions and nothing
  * fetched, large batches step as two chains on two streams that stay forked across calls (the halves of the envs are independent);

@@ -2428,6 +2428,27 @@ int pedn_rl_clock_end(pedn_sim* s, int32_t* t) {
   return PEDN_OK;
 }
 
+int pedn_rl_step_many(pedn_sim** sims, int32_t n, const double* actions, int32_t t, int32_t action_gap, float* obs, float* rewards) {
+  if (!sims || n < 1) return fail(nullptr, PEDN_E_ARG, "no engines");
+  for (int k = 0; k < n; ++k)
+    if (!sims[k] || !sims[k]->rl_ready) return fail(sims[k], PEDN_E_ARG, "null handle or pedn_rl_configure has not been called");
+  size_t row = 0;
+  for (int k = 0; k < n; ++k) {   // every engine's launches first (own stream each: they overlap) ...
+    pedn_sim* s = sims[k];
+    const int rc = pedn_rl_step(s, actions ? actions + row * (size_t)s->rl.A : nullptr, 0, t, action_gap, nullptr, nullptr);
+    if (rc != PEDN_OK) return rc;
+    row += (size_t)s->v.R;
+  }
+  row = 0;
+  for (int k = 0; k < n; ++k) {   // ... then one fetch each
+    pedn_sim* s = sims[k];
+    const int rc = pedn_rl_fetch(s, obs ? obs + row * (size_t)s->rl.O : nullptr, rewards ? rewards + row * (size_t)s->rl.n_agents : nullptr);
+    if (rc != PEDN_OK) return rc;
+    row += (size_t)s->v.R;
+  }
+  return PEDN_OK;
+}
+
 void* pedn_rl_device_ptr(pedn_sim* s, int32_t which) {
   if (!s || !s->rl_ready) return nullptr;
   return which == 0 ? (void*)s->rl.actions : which == 1 ? (void*)s->rl.obs : which == 2 ? (void*)s->rl.rew : nullptr;

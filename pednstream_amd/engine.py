@@ -168,6 +168,7 @@ def _load():
         "pedn_rl_apply_actions": (C.c_int, [P, C.c_void_p, C.c_int32]),
         "pedn_rl_observe": (C.c_int, [P, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
         "pedn_rl_fetch": (C.c_int, [P, C.c_void_p, C.c_void_p]),
+        "pedn_rl_step_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
         "pedn_rl_step": (C.c_int, [P, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
         "pedn_rl_device_ptr": (C.c_void_p, [P, C.c_int32]),
         "pedn_rl_clock_begin": (C.c_int, [P, C.c_int32]),
@@ -203,7 +204,7 @@ EXPORTS = ["pedn_abi_version", "pedn_last_error", "pedn_create", "pedn_destroy",
            "pedn_set_od_weights", "pedn_set_turning_fractions", "pedn_get_turning_fractions", "pedn_set_width",
            "pedn_set_widths", "pedn_step", "pedn_run", "pedn_synchronize", "pedn_error_flags", "pedn_read",
            "pedn_device_ptr", "pedn_history_rows", "pedn_stream", "pedn_timer_begin", "pedn_timer_end", "pedn_reset", "pedn_reset_lazy", "pedn_device_math", "pedn_profile_step", "pedn_profile_run", "pedn_profile_timeline", "pedn_set_streams", "pedn_plan_info", "pedn_rl_configure",
-           "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_fetch", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
+           "pedn_rl_apply_actions", "pedn_rl_observe", "pedn_rl_fetch", "pedn_rl_step_many", "pedn_rl_step", "pedn_rl_device_ptr", "pedn_get_widths", "pedn_set_link_params",
            "pedn_set_od_weights_per_replica", "pedn_get_od_weights_per_replica", "pedn_get_link_params", "pedn_randomize_scenarios", "pedn_reset_widths",
            "pedn_flush", "pedn_rl_clock_begin", "pedn_rl_step_clocked", "pedn_rl_clock_end", "pedn_rl_clocked", "pedn_rl_clock_signature"]
 
@@ -480,6 +481,24 @@ class Engine:
         obs = np.empty((self.n_replicas, self.rl_n_obs), dtype=np.float32)
         rew = np.empty((self.n_replicas, self.rl_n_agents), dtype=np.float32)
         self._ck(self._lib.pedn_rl_observe(self._h, int(t), int(accumulate), obs.ctypes.data_as(C.c_void_p), rew.ctypes.data_as(C.c_void_p)))
+        return obs, rew
+
+    @staticmethod
+    def rl_step_many(engines, actions, t, action_gap=1):
+        """pedn_rl_step_many: one env step of SEVERAL engines (same step index, same agent layout) and their observations / rewards in
+        one library call; rows are the engines' replicas one after the other."""
+        e0 = engines[0]
+        n_rows = sum(e.n_replicas for e in engines)
+        handles = (C.c_void_p * len(engines))(*[e._h for e in engines])
+        a = None if actions is None else np.ascontiguousarray(actions, dtype=np.float64)
+        if a is not None:
+            assert a.shape == (n_rows, e0.rl_n_actions), a.shape
+        obs = np.empty((n_rows, e0.rl_n_obs), dtype=np.float32)
+        rew = np.empty((n_rows, e0.rl_n_agents), dtype=np.float32)
+        rc = e0._lib.pedn_rl_step_many(handles, len(engines), None if a is None else a.ctypes.data_as(C.c_void_p), int(t), int(action_gap),
+                                       obs.ctypes.data_as(C.c_void_p), rew.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise RuntimeError(f"pedn_rl_step_many failed ({rc}): {e0._lib.pedn_last_error(None).decode()}")
         return obs, rew
 
     def rl_fetch(self):

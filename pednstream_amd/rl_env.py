@@ -652,13 +652,20 @@ class MultiScenarioVecEnv:
         return np.concatenate(obs, axis=0), {}
 
     def step(self, actions):
+        from .engine import Engine
+
         actions = np.asarray(actions, dtype=np.float64)
-        offs = np.concatenate([[0], np.cumsum(self.sizes)])
-        jobs = [(g, actions[offs[k]:offs[k + 1]]) for k, g in enumerate(self.groups)]
-        for g, a in jobs:                                   # every group's launches first (own engine, own stream: they overlap) ...
-            g.step_async(a)
-        outs = [g.step_wait() for g in self.groups]         # ... then one fetch each.  (Issued from 2-16 host threads instead: slower.)
-        return (np.concatenate([o[0] for o in outs], axis=0), np.concatenate([o[1] for o in outs], axis=0), outs[0][2], False, {})
+        g0 = self.groups[0]
+        if g0.sim_step + g0.action_gap - 1 > g0.simulation_steps:
+            raise IndexError("episode is over; call reset()")
+        # every group's launches first (own engine, own stream: they overlap), then one fetch each -- in ONE library call
+        # (pedn_rl_step_many; group by group from Python: 33 us per engine and step; from 2-16 host threads: slower still)
+        obs, rew = Engine.rl_step_many([g.network._flush() for g in self.groups], actions, g0.sim_step, g0.action_gap)
+        for g in self.groups:
+            g.sim_step += g.action_gap
+            g.network.current_step = g.sim_step - 1
+            g.network._widths_stale = True
+        return obs, rew, (g0.sim_step - 1) >= g0.simulation_steps, False, {}
 
     def close(self):
         for g in self.groups:
